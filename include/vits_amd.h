@@ -1,0 +1,126 @@
+/*
+ * vits_amd.h - C ABI of the MI355X (gfx950) VITS generator-inference kernels.
+ *
+ * The reference (zassou65535/VITS) has no FFI or operator registry: its hot path is a
+ * set of Python nn.Module.forward methods that call PyTorch ATen ops.  Each entry point
+ * below therefore names the reference forward (file:line under /root/reference) whose
+ * arithmetic it replaces; the Python classes in vits_amd/module mirror those forwards
+ * and call these functions through ctypes.
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer owned by the caller (fp32, time-contiguous
+ *    [batch, channel, time] views described by element strides);
+ *  - functions only enqueue work on `stream` (a hipStream_t passed as void*); they never
+ *    allocate, free or synchronise, so they may be captured into a HIP graph;
+ *  - return value 0 = success, negative = error (VK_E_*); vk_last_error() returns a
+ *    thread-local message for the last failing call on this thread;
+ *  - no mutable global state beyond that thread-local message: calls are re-entrant.
+ */
+#ifndef VITS_AMD_H
+#define VITS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_ABI_VERSION 1
+
+#define VK_OK            0
+#define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
+#define VK_E_UNSUPPORTED -2  /* shape or option outside what the kernels implement */
+#define VK_E_LAUNCH     -3   /* hipLaunchKernel reported an error */
+#define VK_E_WORKSPACE  -4   /* workspace too small */
+
+/* ---- weight packing geometry -------------------------------------------------------
+ * Convolution weights are consumed in "MFMA fragment order": for every 32-row tile of
+ * output channels the K dimension (input-channel chunk, tap, channel pair) is laid out
+ * as a linear stream of 64-lane x 4-float groups, so a wavefront fetches its A operands
+ * with one coalesced 1 KiB load per 4 k-steps.  vits_amd/packing.py produces the layout;
+ * vk_pack_info reports the sizes a packer must honour for a tile family.            */
+typedef struct {
+    int32_t ck;            /* input channels per LDS chunk (K-chunk)                  */
+    int32_t rows_per_block;/* output rows (32 * A_REP * WM) handled by one workgroup  */
+    int32_t time_tile;     /* output columns (time steps) handled by one workgroup    */
+    int32_t a_rep;         /* consecutive 32-row tiles owned by one wavefront         */
+} vk_tile_info;
+
+/* Tile families (vk_conv_args.tile). */
+#define VK_TILE_M128  0   /* 128 rows x 256 cols, 4 waves split rows        (C_out >= 128) */
+#define VK_TILE_M64   1   /*  64 rows x 256 cols, 2x2 waves                 (C_out 64/192) */
+#define VK_TILE_M32   2   /*  32 rows x 512 cols, 4 waves split time        (C_out 32/96)  */
+#define VK_TILE_PAIR  3   /* 128 rows x 256 cols, row tiles in (a,b) pairs  (gated / split outputs) */
+#define VK_TILE_COUNT 4
+
+/* Epilogues (vk_conv_args.epilogue); v = accumulator + bias[row].
+ * Cited lines say which reference statement the epilogue evaluates.                   */
+#define VK_EPI_STORE      0 /* out = v (* mask)                        decoder.py:52,112 flow.py:54 */
+#define VK_EPI_RESID      1 /* out = v + res                           decoder.py:57-58            */
+#define VK_EPI_RESID_ACC  2 /* out = accin + (v + res)                 decoder.py:124              */
+#define VK_EPI_RESID_AVG  3 /* out = (accin + (v + res)) / navg        decoder.py:124-125          */
+#define VK_EPI_GATE       4 /* out = tanh(v_a) * sigmoid(v_b)          wn.py:15-22,73-75           */
+#define VK_EPI_WN_MID     5 /* rows<H: out=(res+v)*mask; rows>=H: out2 (+)= v   wn.py:80-83        */
+#define VK_EPI_WN_LAST    6 /* out2 = (out2 + v) * mask                wn.py:85-86                 */
+#define VK_EPI_COUPLE_REV 7 /* out = (out - v*mask) * mask             flow.py:58,67               */
+#define VK_EPI_COUPLE_FWD 8 /* out = v*mask + out*mask                 flow.py:58,63               */
+#define VK_EPI_UPSAMPLE   9 /* polyphase ConvTranspose1d scatter store decoder.py:117              */
+#define VK_EPI_SAMPLE    10 /* (m,logs) pairs: m, logs, z=(m+eps*exp(logs))*mask  posterior_encoder.py:56-59 */
+#define VK_EPI_COUNT     11
+
+typedef struct {
+    /* input activation view [B, c_in, L] */
+    const float* x;       int64_t x_bstride;   int64_t x_cstride;
+    /* packed weights (fragment order) and bias indexed by ORIGINAL output row */
+    const float* w;
+    const float* bias;    int64_t bias_bstride;      /* 0 = one bias vector for all batch items */
+    /* primary output view */
+    float* out;           int64_t out_bstride; int64_t out_cstride;
+    /* residual / auxiliary input view (same indexing as out unless stated) */
+    const float* res;     int64_t res_bstride; int64_t res_cstride;
+    /* secondary output view (skip accumulator, MRF accumulator, z of VK_EPI_SAMPLE) */
+    float* out2;          int64_t out2_bstride; int64_t out2_cstride;
+    /* third output view (logs of VK_EPI_SAMPLE) and noise input (eps) */
+    float* out3;          const float* aux;
+    const float* mask;    /* [B, L] 0/1 floats or NULL */
+    int32_t batch, c_in, c_out, length;
+    int32_t taps, dilation, pad;  /* x index of tap j for output t: t + j*dilation - pad */
+    int32_t tile, epilogue;
+    int32_t act_in;       /* 1: leaky-ReLU(in_slope) applied to x while staging (decoder.py:49,54,115) */
+    float   in_slope;
+    int32_t first;        /* VK_EPI_WN_MID/LAST: 1 = skip accumulator starts at zero */
+    int32_t hidden;       /* VK_EPI_WN_MID: rows < hidden are the residual half */
+    int32_t up_stride;    /* VK_EPI_UPSAMPLE: stride S (kernel 2S, padding S/2) */
+    float   navg;         /* VK_EPI_RESID_AVG divisor */
+} vk_conv_args;
+
+int         vk_abi_version(void);
+const char* vk_last_error(void);
+int         vk_tile_query(int tile, vk_tile_info* info);
+
+/* Dynamic LDS bytes one workgroup of this launch uses (diagnostic; <= 160 KiB). */
+int64_t     vk_conv1d_lds_bytes(const vk_conv_args* a);
+
+/* Dilated Conv1d / polyphase ConvTranspose1d as implicit GEMM on fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32) with a fused epilogue.
+ * Replaces nn.Conv1d / nn.ConvTranspose1d + surrounding pointwise ops at
+ * decoder.py:49-58,112,115-117 ; wn.py:70-85 ; flow.py:54,58-67 ;
+ * posterior_encoder.py:52,56-59.                                                     */
+int vk_conv1d(const vk_conv_args* a, void* stream);
+
+/* out[b, o] = bias[o] + sum_i W[o, i] * g[b, i]   (speaker-conditioning 1x1 convs on
+ * [B, G, 1] inputs: decoder.py:91,112 `cond`; wn.py:41-42,66 `condition_layer`).
+ * W is [n_out, n_in] row-major (weight norm already folded). One wavefront per output. */
+int vk_speaker_linear(const float* g, const float* w, const float* bias, float* out,
+                      int batch, int n_in, int n_out, void* stream);
+
+/* wav[b, t] = tanh( sum_{c,j} w[c, j] * lrelu(x[b, c, t + j - pad], slope) )
+ * (decoder.py:126-129: leaky_relu(0.01) -> conv1d_post (C->1, k=7, no bias) -> tanh). */
+int vk_post_conv_tanh(const float* x, const float* w, float* wav, int batch, int channels,
+                      int length, int taps, float slope, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITS_AMD_H */

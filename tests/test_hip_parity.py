@@ -1,0 +1,168 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors captured from the reference.  fp32 contract: max-abs 1e-4 on the waveform; the
+tighter gates below are what the fp32 MFMA path actually achieves."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vits_oracle as O
+from vits_amd import synth
+from vits_amd.module.model_component.decoder import Decoder, ResNetBlock
+from vits_amd.module.model_component.flow import Flow, ResidualCouplingLayer
+from vits_amd.module.model_component.posterior_encoder import PosteriorEncoder
+from vits_amd.module.model_component.wn import WN
+from vits_amd.module.vits_generator import HotPathGenerator
+
+pytestmark = pytest.mark.gpu
+SEED = 999
+DEV = "cuda:0"
+CONTRACT = 1e-4     # stated fp32 waveform tolerance
+GATE = 2e-5         # internal gate, relative to max(1, |ref|max)
+
+
+def _gold(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _check(got, ref, tol=GATE, what=""):
+    got = got.detach().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what
+    err = (got - ref).abs().max().item()
+    lim = tol * max(1.0, ref.abs().max().item())
+    assert err <= lim, f"{what}: max-abs {err:.3e} > {lim:.3e}"
+    return err
+
+
+def _load(mod, sd, prefix):
+    mod.load_state_dict(synth.strip_prefix(sd, prefix), strict=True)
+    return mod.to(DEV).eval()
+
+
+@pytest.fixture(scope="module")
+def spk(sd):
+    ids = torch.tensor([9, 57])
+    return O.speaker_embed(ids, sd)
+
+
+def test_resblocks(sd, golden_dir):
+    g3 = _gold(golden_dir, "g3_resblocks.npz")
+    for j, k in enumerate((3, 7, 11)):
+        rb = _load(ResNetBlock(32, k, (1, 3, 5)), sd, f"decoder.resblocks.{9 + j}")
+        x = synth.latent(SEED, f"g3.x{k}", 1, 512, channels=32)
+        y = rb(x.to(DEV))
+        _check(y, g3[f"y{k}"], what=f"resblock k={k} vs golden")
+        _check(y, O.resblock(x, sd, f"decoder.resblocks.{9 + j}", k), what=f"resblock k={k} vs oracle")
+
+
+@pytest.mark.parametrize("channels,length", [(256, 100), (128, 777), (64, 1030)])
+def test_resblock_other_widths(sd, channels, length):
+    r = {256: 0, 128: 3, 64: 6}[channels] + 2          # the k=11 block of that stage
+    rb = _load(ResNetBlock(channels, 11, (1, 3, 5)), sd, f"decoder.resblocks.{r}")
+    x = synth.latent(SEED, f"rbw.{channels}", 2, length, channels=channels)
+    _check(rb(x.to(DEV)), O.resblock(x, sd, f"decoder.resblocks.{r}", 11), what=f"resblock C={channels}")
+
+
+def test_wn_ragged(sd, golden_dir, spk):
+    g4 = _gold(golden_dir, "g4_wn.npz")
+    mask = synth.length_mask([48, 31], 48)
+    for n, pfx in ((4, "flow.flows.0.wn"), (16, "posterior_encoder.wn")):
+        m = _load(WN(192, 5, 1, n, speaker_id_embedding_dim=256), sd, pfx)
+        x = synth.latent(SEED, f"g4.x{n}", 2, 48) * mask
+        y = m(x.to(DEV), mask.to(DEV), spk.to(DEV))
+        _check(y, g4[f"y{n}"], what=f"WN n={n} vs golden")
+
+
+def test_coupling_and_flow(sd, golden_dir, spk):
+    mask = synth.length_mask([48, 31], 48)
+    g5 = _gold(golden_dir, "g5_coupling.npz")
+    rcl = _load(ResidualCouplingLayer(192, 192, 256, 5, 1, 4), sd, "flow.flows.2")
+    x = synth.latent(SEED, "g5.x", 2, 48)
+    _check(rcl(x.to(DEV), mask.to(DEV), spk.to(DEV), False), g5["fwd"], what="coupling fwd")
+    _check(rcl(x.to(DEV), mask.to(DEV), spk.to(DEV), True), g5["rev"], what="coupling rev")
+    g6 = _gold(golden_dir, "g6_flow.npz")
+    fl = _load(Flow(), sd, "flow")
+    x = synth.latent(SEED, "g6.x", 2, 48)
+    _check(fl(x.to(DEV), mask.to(DEV), spk.to(DEV)), g6["fwd"], what="flow fwd")
+    _check(fl(x.to(DEV), mask.to(DEV), spk.to(DEV), reverse=True), g6["rev"], what="flow rev")
+    xm = (x * mask).to(DEV)
+    rt = fl(fl(xm, mask.to(DEV), spk.to(DEV)), mask.to(DEV), spk.to(DEV), reverse=True)
+    _check(rt, xm.cpu(), 1e-5, what="flow round trip")
+
+
+def test_flow_long_ragged(sd):
+    """T not a multiple of any tile, ragged lengths, B=3."""
+    T = 333
+    mask = synth.length_mask([333, 257, 64], T)
+    g = O.speaker_embed(torch.tensor([1, 50, 99]), sd)
+    x = synth.latent(SEED, "flow.long", 3, T)
+    fl = _load(Flow(), sd, "flow")
+    for rev in (False, True):
+        _check(fl(x.to(DEV), mask.to(DEV), g.to(DEV), reverse=rev), O.flow(x, mask, g, sd, reverse=rev),
+               what=f"flow T=333 reverse={rev}")
+
+
+def test_decoder_golden_and_taps(sd, golden_dir):
+    g1 = _gold(golden_dir, "g1_decoder.npz")
+    dec = _load(Decoder(speaker_id_embedding_dim=256), sd, "decoder")
+    z = synth.latent(SEED, "g1.z", 2, 24)
+    g = O.speaker_embed(g1["speakers"], sd)
+    wav = dec(z.to(DEV), g.to(DEV))
+    err = _check(wav, g1["wav"], what="decoder wav vs golden")
+    assert err <= CONTRACT
+    _check(wav, O.decoder(z, g, sd), what="decoder wav vs oracle")
+
+
+def test_decoder_single_item_odd_length(sd):
+    dec = _load(Decoder(speaker_id_embedding_dim=256), sd, "decoder")
+    z = synth.latent(SEED, "dec.odd", 1, 37)
+    g = O.speaker_embed(torch.tensor([3]), sd)
+    _check(dec(z.to(DEV), g.to(DEV)), O.decoder(z, g, sd), what="decoder T=37")
+
+
+def test_posterior_and_voice_conversion(sd, golden_dir, spk):
+    g7 = _gold(golden_dir, "g7_posterior.npz")
+    spec = synth.power_spectrogram(SEED, "g7.spec", 2, 40)
+    pe = _load(PosteriorEncoder(speaker_id_embedding_dim=256), sd, "posterior_encoder")
+    z, m, logs, mask = pe(spec.to(DEV), g7["lengths"].to(DEV), spk.to(DEV), noise=g7["eps"].to(DEV))
+    _check(m, g7["m"], what="posterior mean")
+    _check(logs, g7["logs"], what="posterior log-std")
+    _check(z, g7["z"], 5e-5, what="posterior z")
+    assert torch.equal(mask.cpu(), synth.length_mask(g7["lengths"], 40))
+
+    g9 = _gold(golden_dir, "g9_vc.npz")
+    gen = HotPathGenerator(100)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    wav = gen.voice_conversion(spec.to(DEV), g7["lengths"].to(DEV), g9["src"].to(DEV), g9["tgt"].to(DEV),
+                               noise=g7["eps"].to(DEV))
+    err = _check(wav, g9["wav"], what="voice conversion wav")
+    assert err <= CONTRACT
+
+
+def test_tts_tail(sd, golden_dir, spk):
+    g8 = _gold(golden_dir, "g8_tts_tail.npz")
+    T = 50
+    mask = synth.length_mask([50, 37], T)
+    m_p = synth.latent(SEED, "g8.m_p", 2, T) * 0.5
+    logs_p = synth.latent(SEED, "g8.logs_p", 2, T) * 0.2 - 0.5
+    eps = synth.latent(SEED, "g8.eps", 2, T)
+    gen = HotPathGenerator(100)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    wav = gen.synthesize_from_prior(m_p.to(DEV), logs_p.to(DEV), mask.to(DEV), spk.to(DEV), noise=eps.to(DEV))
+    err = _check(wav, g8["wav"], what="tts tail wav")
+    assert err <= CONTRACT
+
+
+def test_full_size_decoder_checksums(sd, golden_dir):
+    g10 = np.load(os.path.join(golden_dir, "g10_decoder_full_checksums.npz"))
+    dec = _load(Decoder(speaker_id_embedding_dim=256), sd, "decoder")
+    z = synth.latent(SEED, "cfg2.z", 1, 862)
+    wav = dec(z.to(DEV), O.speaker_embed(torch.tensor([9]), sd).to(DEV)).cpu()
+    assert wav.shape == (1, 1, 862 * 256)
+    np.testing.assert_allclose(wav.flatten()[torch.from_numpy(g10["idx"])].numpy(), g10["samples"], atol=GATE)
+    assert abs(wav.double().sum().item() - float(g10["sum"])) < 5e-2
+    assert abs((wav.double() ** 2).sum().item() - float(g10["sumsq"])) < 5e-2

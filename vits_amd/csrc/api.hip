@@ -1,0 +1,116 @@
+// Host side of the C ABI: argument validation, tile geometry, launches.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "conv_launch.hpp"
+#include "api_internal.hpp"
+
+static thread_local char g_err[512] = "";
+
+int vk_fail(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+    return code;
+}
+
+extern "C" int vk_abi_version(void) { return VK_ABI_VERSION; }
+extern "C" const char* vk_last_error(void) { return g_err; }
+
+extern "C" int vk_tile_query(int tile, vk_tile_info* info)
+{
+    if (tile < 0 || tile >= VK_TILE_COUNT || !info) return vk_fail(VK_E_ARG, "vk_tile_query: bad tile id");
+    const TileGeom& G = kTiles[tile];
+    info->ck = G.ck;
+    info->rows_per_block = 32 * G.a_rep * G.wm;
+    info->time_tile = 32 * G.b_rep * G.wn;
+    info->a_rep = G.a_rep;
+    return VK_OK;
+}
+
+// Rows of the implicit GEMM (before padding to the tile's row block).
+static int64_t gemm_rows(const vk_conv_args* a)
+{
+    if (a->epilogue == VK_EPI_UPSAMPLE) return (int64_t)a->c_out * a->up_stride;
+    if (a->epilogue == VK_EPI_GATE || a->epilogue == VK_EPI_SAMPLE) return 2 * (int64_t)a->hidden;
+    return a->c_out;
+}
+
+static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds)
+{
+    if (!a) return vk_fail(VK_E_ARG, "vk_conv1d: null argument block");
+    if (!a->x || !a->w || !a->out) return vk_fail(VK_E_ARG, "vk_conv1d: null x / w / out pointer");
+    if (a->batch <= 0 || a->c_in <= 0 || a->c_out <= 0 || a->length <= 0 || a->taps <= 0 || a->dilation <= 0)
+        return vk_fail(VK_E_ARG, "vk_conv1d: non-positive size");
+    if (a->tile < 0 || a->tile >= VK_TILE_COUNT) return vk_fail(VK_E_ARG, "vk_conv1d: bad tile id");
+    if (a->epilogue < 0 || a->epilogue >= VK_EPI_COUNT) return vk_fail(VK_E_ARG, "vk_conv1d: bad epilogue id");
+    if (a->batch > 65535) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: batch > 65535");
+    const TileGeom& G = kTiles[a->tile];
+    const int TN = 32 * G.b_rep * G.wn;
+    const bool ups = a->epilogue == VK_EPI_UPSAMPLE;
+    const int halo = (a->taps - 1) * a->dilation + (ups ? 1 : 0);
+    if (halo > 64) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: (taps-1)*dilation exceeds the 64-column halo of the LDS tile");
+    if (a->pad < 0 || a->pad > halo) return vk_fail(VK_E_ARG, "vk_conv1d: pad outside [0, (taps-1)*dilation]");
+    switch (a->epilogue) {
+    case VK_EPI_RESID:
+        if (!a->res) return vk_fail(VK_E_ARG, "vk_conv1d: residual epilogue without res"); break;
+    case VK_EPI_RESID_ACC: case VK_EPI_RESID_AVG:
+        if (!a->res || !a->out2) return vk_fail(VK_E_ARG, "vk_conv1d: accumulate epilogue needs res and out2"); break;
+    case VK_EPI_GATE:
+        if (a->hidden <= 0 || a->hidden % 32) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: gate needs hidden % 32 == 0"); break;
+    case VK_EPI_SAMPLE:
+        if (a->hidden <= 0 || a->hidden % 32 || !a->out2 || !a->out3 || !a->aux)
+            return vk_fail(VK_E_ARG, "vk_conv1d: sample epilogue needs hidden % 32 == 0, out2, out3, aux"); break;
+    case VK_EPI_WN_MID:
+        if (!a->res || !a->out2 || a->hidden <= 0 || a->hidden % 32)
+            return vk_fail(VK_E_ARG, "vk_conv1d: WN epilogue needs res, out2 and hidden % 32 == 0"); break;
+    case VK_EPI_WN_LAST:
+        if (!a->out2 && !a->first) return vk_fail(VK_E_ARG, "vk_conv1d: WN last epilogue needs out2"); break;
+    case VK_EPI_COUPLE_REV: case VK_EPI_COUPLE_FWD:
+        if (!a->res || !a->mask) return vk_fail(VK_E_ARG, "vk_conv1d: coupling epilogue needs res and mask"); break;
+    case VK_EPI_UPSAMPLE:
+        if (a->up_stride < 2 || (a->up_stride & 1) || a->taps != 2 || a->dilation != 1 || a->pad != 1)
+            return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: upsample needs even stride, 2 polyphase taps, pad 1");
+        if (a->c_out % (32 * G.a_rep))
+            return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: upsample needs c_out to be a multiple of the wave's row span");
+        break;
+    default: break;
+    }
+    memset(d, 0, sizeof(*d));
+    d->a = *a;
+    d->nchunk = (a->c_in + G.ck - 1) / G.ck;
+    d->xw = TN + halo;
+    d->lds_stride = d->xw;
+    d->groups_per_mt = d->nchunk * a->taps * (G.ck / 8);
+    const int rows_blk = 32 * G.a_rep * G.wm;
+    const int64_t rows = gemm_rows(a);
+    *grid = dim3((unsigned)((a->length + TN - 1) / TN), (unsigned)((rows + rows_blk - 1) / rows_blk), (unsigned)a->batch);
+    *lds = (size_t)2 * G.ck * d->lds_stride * sizeof(float);
+    if (*lds > 160 * 1024) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: LDS tile exceeds 160 KiB");
+    return VK_OK;
+}
+
+extern "C" int64_t vk_conv1d_lds_bytes(const vk_conv_args* a)
+{
+    ConvDev d; dim3 grid; size_t lds = 0;
+    int rc = derive(a, &d, &grid, &lds);
+    return rc == VK_OK ? (int64_t)lds : (int64_t)rc;
+}
+
+extern "C" int vk_conv1d(const vk_conv_args* a, void* stream)
+{
+    ConvDev d; dim3 grid; size_t lds = 0;
+    int rc = derive(a, &d, &grid, &lds);
+    if (rc != VK_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int act = a->act_in ? 1 : 0;
+    int e = -1;
+    switch (a->tile) {
+    case VK_TILE_M128: e = vk_launch_tile0(a->epilogue, act, d, grid, lds, s); break;
+    case VK_TILE_M64:  e = vk_launch_tile1(a->epilogue, act, d, grid, lds, s); break;
+    case VK_TILE_M32:  e = vk_launch_tile2(a->epilogue, act, d, grid, lds, s); break;
+    case VK_TILE_PAIR: e = vk_launch_tile3(a->epilogue, act, d, grid, lds, s); break;
+    }
+    if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: this (tile, epilogue, act_in) combination is not built");
+    if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
+    return VK_OK;
+}

@@ -1,0 +1,45 @@
+// Per-tile launch tables for conv_mfma_kernel.  Each tile family is instantiated in a
+// translation unit of its own (conv_tile_*.hip) so the library builds in parallel.
+#pragma once
+#include "conv_mfma.hpp"
+
+struct TileGeom { int a_rep, b_rep, wm, wn, ck; };
+
+// VK_TILE_M128, VK_TILE_M64, VK_TILE_M32, VK_TILE_PAIR
+static constexpr TileGeom kTiles[VK_TILE_COUNT] = {
+    {1, 8, 4, 1, 32},
+    {1, 4, 2, 2, 32},
+    {1, 4, 1, 4, 16},
+    {2, 4, 2, 2, 32},
+};
+
+// Returns hipSuccess / a HIP error, or -1 when (epilogue, act_in) is not built for the tile.
+int vk_launch_tile0(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile1(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile2(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile3(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+
+#define VK_CONV_CASE(EPI, ACT)                                                                   \
+    if (epi == (EPI) && act == (ACT)) {                                                          \
+        auto k = conv_mfma_kernel<G.a_rep, G.b_rep, G.wm, G.wn, G.ck, (EPI), (ACT) != 0>;        \
+        if (lds > 65536) {                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                  \
+        }                                                                                        \
+        hipLaunchKernelGGL(k, grid, dim3(64 * G.wm * G.wn), lds, s, d);                          \
+        return (int)hipGetLastError();                                                           \
+    }
+
+#define VK_PLAIN_TILE_BODY()                  \
+    VK_CONV_CASE(VK_EPI_STORE, 0)             \
+    VK_CONV_CASE(VK_EPI_STORE, 1)             \
+    VK_CONV_CASE(VK_EPI_RESID, 1)             \
+    VK_CONV_CASE(VK_EPI_RESID_ACC, 1)         \
+    VK_CONV_CASE(VK_EPI_RESID_AVG, 1)         \
+    VK_CONV_CASE(VK_EPI_UPSAMPLE, 1)          \
+    VK_CONV_CASE(VK_EPI_WN_MID, 0)            \
+    VK_CONV_CASE(VK_EPI_WN_LAST, 0)           \
+    VK_CONV_CASE(VK_EPI_COUPLE_REV, 0)        \
+    VK_CONV_CASE(VK_EPI_COUPLE_FWD, 0)        \
+    return -1;

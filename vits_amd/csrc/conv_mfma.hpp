@@ -1,0 +1,274 @@
+// Implicit-GEMM Conv1d / polyphase ConvTranspose1d on the gfx950 fp32 matrix cores.
+//
+//   out[row, t] = sum_{c, j} W[row, c, j] * act(x[c, t + j*dilation - pad])   (+ fused epilogue)
+//
+// GEMM view: M = output rows (channels, or phase*channels for the transposed conv),
+// N = time, K = (input channel, tap).  One workgroup owns 32*A_REP*WM rows by
+// 32*B_REP*WN time steps.  The activation tile (CK input channels by time tile + halo) is
+// staged through LDS once per K-chunk, double buffered, with the leaky-ReLU applied while
+// staging; every tap of the convolution then reads it at a shifted column, so nothing is
+// re-fetched from HBM per tap and no im2col matrix exists.  Weights arrive pre-packed in
+// fragment order (see packing.py) and stream straight from L2 into registers, one 16-byte
+// load per lane per four k-steps, prefetched one group ahead.
+//
+// Matrix instruction: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  Operand maps:
+//   A: lane l holds A[row = l & 31][k = l >> 5]        (k = channel within the pair)
+//   B: lane l holds B[k = l >> 5][col = l & 31]        (col = time)
+//   D: register r of lane l is D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
+// Time is the lane dimension everywhere, so LDS reads, global loads and stores are
+// contiguous in time.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vits_amd.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvDev {
+    vk_conv_args a;
+    int nchunk;         // K-chunks: ceil(c_in / CK)
+    int xw;             // staged columns per row: time tile + halo
+    int lds_stride;     // floats between staged rows
+    int groups_per_mt;  // 64-lane x float4 groups per 32-row tile: nchunk * taps * CK / 8
+};
+
+__device__ __forceinline__ float vk_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT>
+__global__ void __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN)) > 0 ? (512 / (64 * WM * WN)) : 1)
+conv_mfma_kernel(const ConvDev d)
+{
+    constexpr int NW  = WM * WN;
+    constexpr int TNW = 32 * B_REP;          // time steps per wave
+    constexpr int TN  = TNW * WN;            // time steps per workgroup
+    constexpr int NJ  = TN / 64 + 1;         // 64-column pieces per staged row (halo <= 64)
+    constexpr int RPW = CK / NW;             // staged rows per wave per chunk
+    constexpr int GPC = CK / 8;              // weight groups per (chunk, tap)
+    static_assert(CK % NW == 0 && CK % 8 == 0, "chunk must split over waves and k-groups");
+    static_assert(TN % 64 == 0, "time tile must be a multiple of the wave width");
+    constexpr bool PAIR = (EPI == VK_EPI_GATE || EPI == VK_EPI_SAMPLE);
+    static_assert(!PAIR || (A_REP % 2 == 0), "paired epilogues need an even number of row tiles per wave");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const vk_conv_args& p = d.a;
+    const int lane = threadIdx.x & 63;
+    const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm   = w % WM;
+    const int wn   = w / WM;
+    const int half = lane >> 5;
+    const int l31  = lane & 31;
+    const int b    = blockIdx.z;
+    const int t0   = blockIdx.x * TN;
+    const int mt0  = (blockIdx.y * WM + wm) * A_REP;   // first packed 32-row tile of this wave
+    const int L    = p.length;
+    const int ts   = t0 - p.pad;                       // time of staged column 0
+    const int stride = d.lds_stride;
+
+    const float* xb = p.x + (int64_t)b * p.x_bstride;
+
+    // ---- staging: global -> registers (issued early) -> LDS (written after the barrier) ----
+    float stage[RPW][NJ];
+    auto issue_loads = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int c = chunk * CK + w + r * NW;
+            const float* row = xb + (int64_t)(c < p.c_in ? c : 0) * p.x_cstride;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                int t = ts + lane + 64 * j;
+                t = t < 0 ? 0 : (t >= L ? L - 1 : t);      // clamp: the select happens at store time
+                stage[r][j] = row[t];
+            }
+        }
+    };
+    auto store_chunk = [&](int chunk, float* buf) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int cl = w + r * NW;
+            const bool cok = (chunk * CK + cl) < p.c_in;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = lane + 64 * j;
+                const int t = ts + col;
+                float v = (cok && t >= 0 && t < L) ? stage[r][j] : 0.0f;
+                if (ACT) v = v > 0.0f ? v : v * p.in_slope;
+                if (col < d.xw) buf[cl * stride + col] = v;
+            }
+        }
+    };
+
+    // ---- weight stream: one float4 per lane per 4 k-steps per row tile ----
+    const float4* aptr[A_REP];
+#pragma unroll
+    for (int m = 0; m < A_REP; ++m)
+        aptr[m] = reinterpret_cast<const float4*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
+
+    f32x16 acc[A_REP][B_REP];
+#pragma unroll
+    for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+        for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    // transposed conv: row tiles of the upper phases read the staged tile one column later
+    int shift = 0;
+    if (EPI == VK_EPI_UPSAMPLE) {
+        const int phase = (mt0 * 32) / p.c_out;
+        shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
+    }
+    const int bcol = half * stride + wn * TNW + l31 + shift;
+
+    float4 a_next[A_REP];
+#pragma unroll
+    for (int m = 0; m < A_REP; ++m) a_next[m] = *aptr[m];
+
+    issue_loads(0);
+    for (int chunk = 0; chunk < d.nchunk; ++chunk) {
+        float* buf = lds + (chunk & 1) * (CK * stride);
+        store_chunk(chunk, buf);
+        __syncthreads();
+        if (chunk + 1 < d.nchunk) issue_loads(chunk + 1);
+
+        for (int tap = 0; tap < p.taps; ++tap) {
+            const float* bt = buf + bcol + tap * p.dilation;
+#pragma unroll
+            for (int g = 0; g < GPC; ++g) {
+                float4 a_cur[A_REP];
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) {
+                    a_cur[m] = a_next[m];
+                    aptr[m] += 64;
+                    a_next[m] = *aptr[m];          // packed buffer carries one spare group at its end
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* bk = bt + (2 * (4 * g + e)) * stride;
+                    float bf[B_REP];
+#pragma unroll
+                    for (int n = 0; n < B_REP; ++n) bf[n] = bk[32 * n];
+#pragma unroll
+                    for (int m = 0; m < A_REP; ++m) {
+                        const float av = (e == 0) ? a_cur[m].x : (e == 1) ? a_cur[m].y
+                                       : (e == 2) ? a_cur[m].z : a_cur[m].w;
+#pragma unroll
+                        for (int n = 0; n < B_REP; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------------------------- epilogue ----------------------------------------
+    const int tw = t0 + wn * TNW + l31;                 // this lane's time for n = 0
+    const int64_t ob  = (int64_t)b * p.out_bstride;
+    const int64_t rb  = (int64_t)b * p.res_bstride;
+    const int64_t o2b = (int64_t)b * p.out2_bstride;
+    const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
+
+    float mk[B_REP];
+#pragma unroll
+    for (int n = 0; n < B_REP; ++n) {
+        const int t = tw + 32 * n;
+        mk[n] = (p.mask != nullptr && t < L) ? p.mask[(int64_t)b * L + t] : 1.0f;
+    }
+
+    if constexpr (PAIR) {
+        // packed row tiles alternate (a, b): a = rows [32q, 32q+32), b = rows [hidden + 32q, ...)
+#pragma unroll
+        for (int m = 0; m < A_REP; m += 2) {
+            const int q = (mt0 + m) >> 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= p.hidden) continue;
+                const float ba = biasb ? biasb[row] : 0.0f;
+                const float bb = biasb ? biasb[p.hidden + row] : 0.0f;
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n) {
+                    const int t = tw + 32 * n;
+                    if (t >= L) continue;
+                    const float va = acc[m][n][r] + ba;
+                    const float vb = acc[m + 1][n][r] + bb;
+                    const int64_t o = ob + (int64_t)row * p.out_cstride + t;
+                    if constexpr (EPI == VK_EPI_GATE) {
+                        p.out[o] = tanhf(va) * vk_sigmoid(vb);
+                    } else {   // VK_EPI_SAMPLE: out = mean, out3 = log-std, out2 = sampled latent
+                        const float mean = va * mk[n];
+                        const float logs = vb * mk[n];
+                        p.out[o]  = mean;
+                        p.out3[o] = logs;
+                        p.out2[o2b + (int64_t)row * p.out2_cstride + t] = (mean + p.aux[o] * expf(logs)) * mk[n];
+                    }
+                }
+            }
+        }
+    } else if constexpr (EPI == VK_EPI_UPSAMPLE) {
+        const int S = p.up_stride;
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) {
+            const int prow0 = (mt0 + m) * 32;
+            const int phase = prow0 / p.c_out;
+            if (phase >= S) continue;
+            const int co0 = prow0 - phase * p.c_out;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float bv = biasb ? biasb[co] : 0.0f;
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n) {
+                    const int t = tw + 32 * n;
+                    if (t >= L) continue;
+                    p.out[(int64_t)b * p.out_bstride + (int64_t)co * p.out_cstride + (int64_t)t * S + phase] = acc[m][n][r] + bv;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= p.c_out) continue;
+                const float bv = biasb ? biasb[row] : 0.0f;
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n) {
+                    const int t = tw + 32 * n;
+                    if (t >= L) continue;
+                    const float v = acc[m][n][r] + bv;
+                    if constexpr (EPI == VK_EPI_STORE) {
+                        p.out[ob + (int64_t)row * p.out_cstride + t] = v * mk[n];
+                    } else if constexpr (EPI == VK_EPI_RESID) {
+                        p.out[ob + (int64_t)row * p.out_cstride + t] = v + p.res[rb + (int64_t)row * p.res_cstride + t];
+                    } else if constexpr (EPI == VK_EPI_RESID_ACC || EPI == VK_EPI_RESID_AVG) {
+                        const float y = v + p.res[rb + (int64_t)row * p.res_cstride + t];
+                        const int64_t o2 = o2b + (int64_t)row * p.out2_cstride + t;
+                        float s = p.out2[o2] + y;
+                        if constexpr (EPI == VK_EPI_RESID_AVG) s = s / p.navg;
+                        p.out[ob + (int64_t)row * p.out_cstride + t] = s;
+                    } else if constexpr (EPI == VK_EPI_WN_MID) {
+                        if (row < p.hidden) {
+                            const int64_t o = ob + (int64_t)row * p.out_cstride + t;
+                            p.out[o] = (p.res[rb + (int64_t)row * p.res_cstride + t] + v) * mk[n];
+                        } else {
+                            const int64_t o2 = o2b + (int64_t)(row - p.hidden) * p.out2_cstride + t;
+                            p.out2[o2] = p.first ? v : p.out2[o2] + v;
+                        }
+                    } else if constexpr (EPI == VK_EPI_WN_LAST) {
+                        const int64_t o2 = o2b + (int64_t)row * p.out2_cstride + t;
+                        const float s = p.first ? v : p.out2[o2] + v;
+                        p.out[ob + (int64_t)row * p.out_cstride + t] = s * mk[n];
+                    } else if constexpr (EPI == VK_EPI_COUPLE_REV) {
+                        const int64_t o = ob + (int64_t)row * p.out_cstride + t;
+                        p.out[o] = (p.res[rb + (int64_t)row * p.res_cstride + t] - v * mk[n]) * mk[n];
+                    } else if constexpr (EPI == VK_EPI_COUPLE_FWD) {
+                        const int64_t o = ob + (int64_t)row * p.out_cstride + t;
+                        p.out[o] = v * mk[n] + p.res[rb + (int64_t)row * p.res_cstride + t] * mk[n];
+                    }
+                }
+            }
+        }
+    }
+}

@@ -1,0 +1,180 @@
+"""HiFi-GAN decoder: latent z [B,192,T] + speaker embedding -> waveform [B,1,256*T].
+
+Drop-in for /root/reference/module/model_component/decoder.py (``ResNetBlock`` :23-61,
+``Decoder`` :64-131): same constructor arguments, ``forward`` signatures and ``state_dict``
+keys (``conv1d_pre``, ``cond``, ``ups.{i}``, ``resblocks.{r}.convs{1,2}.{j}``,
+``conv1d_post``).
+
+Every convolution is one launch of the fp32-MFMA implicit-GEMM kernel with the
+surrounding pointwise work fused in:
+  * leaky-ReLU (decoder.py:49,54,115) is applied while the input tile is staged to LDS;
+  * bias, the residual add (decoder.py:58), the sum over the three resblocks of a stage
+    and the division by their number (decoder.py:119-125) are epilogues;
+  * ConvTranspose1d (kernel 2*stride, padding stride/2) runs as a 2-tap polyphase
+    convolution with stride*C_out GEMM rows, each output sample written once;
+  * ``cond(g)`` (decoder.py:112) is a GEMV whose result becomes a per-utterance bias of
+    ``conv1d_pre``;
+  * weight norm is folded once per parameter version, not per forward.
+The output stage (leaky-ReLU 0.01 -> conv 32->1 -> tanh, decoder.py:126-129) is a small
+bandwidth-bound kernel of its own.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ... import native, packing
+from ...engine import PackedConv, PlainConvParams, PlanCache, WeightNormConvParams, require_device
+
+LRELU_SLOPE = 0.1
+
+
+def get_padding(kernel_size, dilation=1):
+    return int((kernel_size - 1) * dilation / 2)
+
+
+class ResBlockPlan:
+    def __init__(self, rb: "ResNetBlock", device):
+        self.pairs = []
+        for j, d in enumerate(rb.dilation):
+            c1, c2 = rb.convs1[j], rb.convs2[j]
+            self.pairs.append((PackedConv(c1.effective_weight(), c1.bias, device, dilation=d),
+                               PackedConv(c2.effective_weight(), c2.bias, device, dilation=1)))
+
+    def run(self, x, tmp, run_buf, final_out, final_epi, acc_in=None, navg=1.0):
+        """x -> resblock(x).  The last conv writes ``final_out`` with ``final_epi`` (plain
+        residual, or residual + accumulation over resblocks); earlier pairs update ``run_buf``."""
+        C = x.shape[1]
+        cur = x
+        last = len(self.pairs) - 1
+        for j, (c1, c2) in enumerate(self.pairs):
+            native.conv1d(cur, c1.w, tmp, c_in=C, c_out=C, taps=c1.taps, dilation=c1.dilation, pad=c1.pad,
+                          tile=c1.tile, epilogue=native.EPI_STORE, bias=c1.bias,
+                          act_in=True, in_slope=LRELU_SLOPE)
+            if j < last:
+                native.conv1d(tmp, c2.w, run_buf, c_in=C, c_out=C, taps=c2.taps, dilation=1, pad=c2.pad,
+                              tile=c2.tile, epilogue=native.EPI_RESID, bias=c2.bias, res=cur,
+                              act_in=True, in_slope=LRELU_SLOPE)
+                cur = run_buf
+            else:
+                native.conv1d(tmp, c2.w, final_out, c_in=C, c_out=C, taps=c2.taps, dilation=1, pad=c2.pad,
+                              tile=c2.tile, epilogue=final_epi, bias=c2.bias, res=cur, out2=acc_in,
+                              act_in=True, in_slope=LRELU_SLOPE, navg=navg)
+        return final_out
+
+
+class ResNetBlock(nn.Module):
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.channels, self.kernel_size, self.dilation = channels, kernel_size, tuple(dilation)
+        self.convs1 = nn.ModuleList(WeightNormConvParams(channels, channels, kernel_size) for _ in self.dilation)
+        self.convs2 = nn.ModuleList(WeightNormConvParams(channels, channels, kernel_size) for _ in self.dilation)
+        self._plans = PlanCache(self, lambda dev: ResBlockPlan(self, dev))
+
+    def plan(self, device) -> ResBlockPlan:
+        return self._plans.get(device)
+
+    @torch.no_grad()
+    def forward(self, x, x_mask=None):
+        require_device(x, "ResNetBlock.forward")
+        if x_mask is not None:
+            raise native.NativeError("ResNetBlock: x_mask is never used on the inference path "
+                                     "(decoder.py:122) and is not implemented in the HIP path")
+        x = x.to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        return self.plan(x.device).run(x, torch.empty_like(x), out, out, native.EPI_RESID)
+
+
+class DecoderPlan:
+    def __init__(self, dec: "Decoder", device):
+        pre = dec.conv1d_pre
+        self.pre = PackedConv(pre.effective_weight(), None, device)
+        self.cond_w = dec.cond.weight.detach().to(device)[:, :, 0].contiguous()
+        self.cond_b = (dec.cond.bias.detach() + pre.bias.detach()).to(device).contiguous()
+        self.ups = []
+        for i, (s, k) in enumerate(zip(dec.deconv_strides, dec.deconv_kernel_sizes)):
+            up = dec.ups[i]
+            wt = up.effective_weight().to(device)
+            poly = packing.transposed_to_polyphase(wt, s)
+            self.ups.append((PackedConv(poly, up.bias, device, pad=1), s, wt.shape[1]))
+        self.resblocks = [rb.plan(device) for rb in dec.resblocks]
+        self.post_w = dec.conv1d_post.weight.detach().to(device)[0].contiguous()    # [C, taps]
+
+
+class Decoder(nn.Module):
+    def __init__(self, speaker_id_embedding_dim, in_z_channel=192, upsample_initial_channel=512,
+                 deconv_strides=[8, 8, 2, 2], deconv_kernel_sizes=[16, 16, 4, 4],
+                 resblock_kernel_sizes=[3, 7, 11],
+                 resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]]):
+        super().__init__()
+        self.speaker_id_embedding_dim = speaker_id_embedding_dim
+        self.in_z_channel = in_z_channel
+        self.upsample_initial_channel = upsample_initial_channel
+        self.deconv_strides = list(deconv_strides)
+        self.deconv_kernel_sizes = list(deconv_kernel_sizes)
+        self.resblock_kernel_sizes = list(resblock_kernel_sizes)
+        self.resblock_dilation_sizes = [list(d) for d in resblock_dilation_sizes]
+        self.num_deconvs = len(self.deconv_strides)
+        self.num_resnet_blocks = len(self.resblock_kernel_sizes)
+        for s, k in zip(self.deconv_strides, self.deconv_kernel_sizes):
+            if k != 2 * s or s % 2:
+                raise ValueError("the polyphase upsampling kernel needs kernel_size == 2*stride, stride even")
+        c0 = upsample_initial_channel
+        self.conv1d_pre = PlainConvParams(in_z_channel, c0, 7)
+        self.cond = PlainConvParams(speaker_id_embedding_dim, c0, 1)
+        self.ups = nn.ModuleList(
+            WeightNormConvParams(c0 // 2 ** i, c0 // 2 ** (i + 1), k, transposed=True)
+            for i, k in enumerate(self.deconv_kernel_sizes))
+        self.resblocks = nn.ModuleList()
+        ch = c0
+        for i in range(self.num_deconvs):
+            ch = c0 // 2 ** (i + 1)
+            for k, d in zip(self.resblock_kernel_sizes, self.resblock_dilation_sizes):
+                self.resblocks.append(ResNetBlock(ch, k, d))
+        self.conv1d_post = PlainConvParams(ch, 1, 7, bias=False)
+        self._plans = PlanCache(self, lambda dev: DecoderPlan(self, dev))
+
+    @torch.no_grad()
+    def forward(self, z, speaker_id_embedded):
+        require_device(z, "Decoder.forward")
+        dev = z.device
+        plan = self._plans.get(dev)
+        z = z.to(torch.float32).contiguous()
+        B, _, T = z.shape
+        g2 = speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous()
+        c0 = self.upsample_initial_channel
+
+        pre_bias = torch.empty(B, c0, device=dev, dtype=torch.float32)
+        native.speaker_linear(g2, plan.cond_w, plan.cond_b, pre_bias)
+        x = torch.empty(B, c0, T, device=dev, dtype=torch.float32)
+        native.conv1d(z, plan.pre.w, x, c_in=self.in_z_channel, c_out=c0, taps=plan.pre.taps, dilation=1,
+                      pad=plan.pre.pad, tile=plan.pre.tile, epilogue=native.EPI_STORE,
+                      bias=pre_bias, bias_bstride=c0)
+
+        L = T
+        nrb = self.num_resnet_blocks
+        for i in range(self.num_deconvs):
+            up, s, cout = plan.ups[i]
+            cin = x.shape[1]
+            L = L * s
+            xu = torch.empty(B, cout, L, device=dev, dtype=torch.float32)
+            native.conv1d(x, up.w, xu, c_in=cin, c_out=cout, taps=2, dilation=1, pad=1, tile=up.tile,
+                          epilogue=native.EPI_UPSAMPLE, bias=up.bias, act_in=True, in_slope=LRELU_SLOPE,
+                          up_stride=s)
+            tmp = torch.empty_like(xu)
+            run_buf = torch.empty_like(xu)
+            xs = torch.empty_like(xu)
+            for j in range(nrb):
+                if nrb == 1:
+                    epi = native.EPI_RESID
+                elif j == 0:
+                    epi = native.EPI_RESID
+                elif j < nrb - 1:
+                    epi = native.EPI_RESID_ACC
+                else:
+                    epi = native.EPI_RESID_AVG
+                plan.resblocks[i * nrb + j].run(xu, tmp, run_buf, xs, epi, acc_in=xs, navg=float(nrb))
+            x = xs
+        wav = torch.empty(B, 1, L, device=dev, dtype=torch.float32)
+        native.post_conv_tanh(x, plan.post_w, wav, 0.01)
+        return wav

@@ -1,0 +1,110 @@
+"""WN: the WaveNet-style gated stack used by the coupling layers and the posterior encoder.
+
+Drop-in for /root/reference/module/model_component/wn.py (``WN`` :26-86,
+``gated_activation_unit`` :15-22): same constructor arguments, same ``forward(x, x_mask,
+speaker_id_embedded)`` and the same ``state_dict`` keys (``in_resblocks.{i}``,
+``res_skip_layers.{i}``, ``condition_layer``, each ``bias / weight_g / weight_v``).
+
+Per layer the reference runs a k-tap conv (H -> 2H), adds the layer's slice of the speaker
+conditioning, gates tanh*sigmoid, runs a 1x1 conv (H -> 2H, last layer H) and splits the
+result into a masked residual update and a skip accumulation.  Here that is two launches
+of the fp32-MFMA convolution kernel: conv + conditioning bias + gate in one epilogue, and
+1x1 conv + residual/skip/mask in the other.  The conditioning 1x1 conv on the [B, G, 1]
+speaker vector is one wavefront-reduced GEMV for all layers, with the in-conv biases
+folded in.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ... import native
+from ...engine import PackedConv, PlanCache, WeightNormConvParams, require_device
+from ...packing import pair_row_order
+
+
+class WNPlan:
+    """Packed weights of one WN stack on one device."""
+
+    def __init__(self, wn: "WN", device):
+        H, n = wn.hidden_channels, wn.n_resblocks
+        order = pair_row_order(H).to(device)
+        self.hidden, self.n_layers = H, n
+        self.in_convs, self.rs_convs = [], []
+        cond_bias = wn.condition_layer.bias.detach().to(device).clone()
+        for i in range(n):
+            m = wn.in_resblocks[i]
+            dil = wn.dilation_rate ** i
+            self.in_convs.append(PackedConv(m.effective_weight(), None, device, tile=native.TILE_PAIR,
+                                            row_order=order, dilation=dil, rows=2 * H))
+            cond_bias[2 * H * i:2 * H * (i + 1)] += m.bias.detach().to(device)
+            r = wn.res_skip_layers[i]
+            self.rs_convs.append(PackedConv(r.effective_weight(), r.bias, device))
+        # conditioning GEMV: rows = 2H * n, in-conv biases folded into its bias
+        self.cond_w = wn.condition_layer.effective_weight().to(device)[:, :, 0].contiguous()
+        self.cond_b = cond_bias.contiguous()
+
+    def conditioning(self, g2: torch.Tensor) -> torch.Tensor:
+        """g2 [B, G] -> per-(batch, layer) gate biases [B, n_layers * 2H]."""
+        out = torch.empty(g2.shape[0], self.cond_w.shape[0], device=g2.device, dtype=torch.float32)
+        native.speaker_linear(g2, self.cond_w, self.cond_b, out)
+        return out
+
+    def run(self, x: torch.Tensor, mask2: torch.Tensor, cond: torch.Tensor, cond_offset: int = 0,
+            out: torch.Tensor | None = None) -> torch.Tensor:
+        """x [B,H,T] is consumed (updated in place); mask2 [B,T]; cond [B, *] holds this
+        stack's gate biases starting at column ``cond_offset``.  Returns the masked skip sum."""
+        B, H, T = x.shape
+        acts = torch.empty_like(x)
+        skip = torch.empty_like(x)
+        if out is None:
+            out = torch.empty_like(x)
+        cstride = cond.stride(0)
+        for i in range(self.n_layers):
+            ic, rc = self.in_convs[i], self.rs_convs[i]
+            bias_view = cond[:, cond_offset + 2 * H * i:]
+            native.conv1d(x, ic.w, acts, c_in=H, c_out=2 * H, taps=ic.taps, dilation=ic.dilation,
+                          pad=ic.pad, tile=ic.tile, epilogue=native.EPI_GATE, bias=bias_view,
+                          bias_bstride=cstride, hidden=H)
+            if i < self.n_layers - 1:
+                native.conv1d(acts, rc.w, x, c_in=H, c_out=2 * H, taps=1, dilation=1, pad=0, tile=rc.tile,
+                              epilogue=native.EPI_WN_MID, bias=rc.bias, res=x, out2=skip, mask=mask2,
+                              first=(i == 0), hidden=H)
+            else:
+                native.conv1d(acts, rc.w, out, c_in=H, c_out=H, taps=1, dilation=1, pad=0, tile=rc.tile,
+                              epilogue=native.EPI_WN_LAST, bias=rc.bias, out2=skip, mask=mask2,
+                              first=(i == 0), hidden=H)
+        return out
+
+
+class WN(nn.Module):
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_resblocks, speaker_id_embedding_dim):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        if hidden_channels % 32 != 0:
+            raise ValueError("hidden_channels must be a multiple of 32 for the MFMA row tiles")
+        self.hidden_channels = hidden_channels
+        self.kernel_size = kernel_size
+        self.dilation_rate = dilation_rate
+        self.n_resblocks = n_resblocks
+        self.speaker_id_embedding_dim = speaker_id_embedding_dim
+        self.in_resblocks = nn.ModuleList(
+            WeightNormConvParams(hidden_channels, 2 * hidden_channels, kernel_size) for _ in range(n_resblocks))
+        self.res_skip_layers = nn.ModuleList(
+            WeightNormConvParams(hidden_channels, 2 * hidden_channels if i < n_resblocks - 1 else hidden_channels, 1)
+            for i in range(n_resblocks))
+        self.condition_layer = WeightNormConvParams(speaker_id_embedding_dim, 2 * hidden_channels * n_resblocks, 1)
+        self._plans = PlanCache(self, lambda dev: WNPlan(self, dev))
+
+    def plan(self, device) -> WNPlan:
+        return self._plans.get(device)
+
+    @torch.no_grad()
+    def forward(self, x, x_mask, speaker_id_embedded):
+        require_device(x, "WN.forward")
+        plan = self.plan(x.device)
+        B, H, T = x.shape
+        mask2 = x_mask.to(torch.float32).expand(B, 1, T).reshape(B, T).contiguous()
+        cond = plan.conditioning(speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous())
+        work = x.to(torch.float32).clone(memory_format=torch.contiguous_format)
+        return plan.run(work, mask2, cond)

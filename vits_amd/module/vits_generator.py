@@ -1,0 +1,86 @@
+"""Generator facade: speaker table + posterior encoder + flow + decoder, inference methods.
+
+Mirrors the inference half of /root/reference/module/vits_generator.py: ``VitsGenerator``
+(:67-125), ``text_to_speech`` (:168-187), ``voice_conversion`` (:189-197), ``sequence_mask``
+(:39-43) and ``generate_path`` (:45-64).  The hot path proper - reverse flow then decoder
+(:185-186), and for voice conversion posterior encoder -> forward flow -> reverse flow ->
+decoder (:193-196) - runs on the HIP kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .model_component.decoder import Decoder
+from .model_component.flow import Flow
+from .model_component.posterior_encoder import PosteriorEncoder
+
+
+def sequence_mask(length, max_length=None):
+    if max_length is None:
+        max_length = length.max()
+    steps = torch.arange(max_length, dtype=length.dtype, device=length.device)
+    return steps.unsqueeze(0) < length.unsqueeze(1)
+
+
+def generate_path(duration, mask):
+    """duration [B,1,Tx] (integer-valued), mask [B,1,Ty,Tx] -> hard monotonic alignment
+    [B,1,Ty,Tx]: frame y belongs to token x iff cum[x-1] <= y < cum[x]."""
+    b, _, t_y, t_x = mask.shape
+    cum = torch.cumsum(duration, -1).view(b * t_x)
+    upto = sequence_mask(cum, t_y).to(mask.dtype).view(b, t_x, t_y)
+    prev = torch.cat([torch.zeros_like(upto[:, :1]), upto[:, :-1]], dim=1)
+    return (upto - prev).unsqueeze(1).transpose(2, 3) * mask
+
+
+class HotPathGenerator(nn.Module):
+    """The sub-modules the hot path needs, with the reference's attribute names and
+    ``state_dict`` prefixes (``speaker_embedding``, ``posterior_encoder``, ``decoder``, ``flow``)."""
+
+    def __init__(self, n_speakers: int, with_posterior: bool = True):
+        super().__init__()
+        self.n_speakers = n_speakers
+        self.z_channels = 192
+        self.spec_channels = 513
+        self.phoneme_embedding_dim = 192
+        self.speaker_id_embedding_dim = 256
+        self.speaker_embedding = nn.Embedding(n_speakers, self.speaker_id_embedding_dim)
+        if with_posterior:
+            self.posterior_encoder = PosteriorEncoder(
+                speaker_id_embedding_dim=self.speaker_id_embedding_dim, in_spec_channels=self.spec_channels,
+                out_z_channels=self.z_channels, phoneme_embedding_dim=self.phoneme_embedding_dim)
+        self.decoder = Decoder(speaker_id_embedding_dim=self.speaker_id_embedding_dim,
+                               in_z_channel=self.z_channels)
+        self.flow = Flow(speaker_id_embedding_dim=self.speaker_id_embedding_dim,
+                         in_z_channels=self.z_channels, phoneme_embedding_dim=self.phoneme_embedding_dim)
+
+    @torch.no_grad()
+    def embed_speaker(self, speaker_id):
+        return self.speaker_embedding(speaker_id).unsqueeze(-1)
+
+    @torch.no_grad()
+    def synthesize_from_prior(self, m_p, logs_p, spec_mask, speaker_id_embedded, noise=None,
+                              noise_scale=.667, max_len=None):
+        """Lines 184-186 of the reference's ``text_to_speech``: sample z_p from the frame-rate
+        prior, invert the flow, decode.  ``noise`` pins the ``randn_like`` draw."""
+        if noise is None:
+            noise = torch.randn_like(m_p)
+        z_p = m_p + noise * torch.exp(logs_p) * noise_scale
+        z = self.flow(z_p, spec_mask, speaker_id_embedded=speaker_id_embedded, reverse=True)
+        return self.decoder((z * spec_mask)[:, :, :max_len], speaker_id_embedded=speaker_id_embedded)
+
+    @torch.no_grad()
+    def flow_reverse_decode(self, z_p, spec_mask, speaker_id_embedded):
+        z = self.flow(z_p, spec_mask, speaker_id_embedded=speaker_id_embedded, reverse=True)
+        return self.decoder(z * spec_mask, speaker_id_embedded=speaker_id_embedded)
+
+    @torch.no_grad()
+    def voice_conversion(self, spec_padded, spec_lengths, source_speaker_id, target_speaker_id, noise=None):
+        assert self.n_speakers > 0
+        emb_source = self.embed_speaker(source_speaker_id)
+        emb_target = self.embed_speaker(target_speaker_id)
+        z, _, _, spec_mask = self.posterior_encoder(spec_padded, spec_lengths,
+                                                    speaker_id_embedded=emb_source, noise=noise)
+        z_p = self.flow(z, spec_mask, speaker_id_embedded=emb_source)
+        z_hat = self.flow(z_p, spec_mask, speaker_id_embedded=emb_target, reverse=True)
+        return self.decoder(z_hat * spec_mask, speaker_id_embedded=emb_target)

@@ -1,0 +1,152 @@
+"""ctypes binding of libvits_amd.so (the C ABI declared in include/vits_amd.h).
+
+There is no CPU fallback: if the library is missing, or a call fails, an exception is
+raised.  Build the library with ``python -m vits_amd.build`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvits_amd.so")
+
+TILE_M128, TILE_M64, TILE_M32, TILE_PAIR = 0, 1, 2, 3
+(EPI_STORE, EPI_RESID, EPI_RESID_ACC, EPI_RESID_AVG, EPI_GATE, EPI_WN_MID, EPI_WN_LAST,
+ EPI_COUPLE_REV, EPI_COUPLE_FWD, EPI_UPSAMPLE, EPI_SAMPLE) = range(11)
+
+_fp = C.c_void_p
+
+
+class TileInfo(C.Structure):
+    _fields_ = [("ck", C.c_int32), ("rows_per_block", C.c_int32),
+                ("time_tile", C.c_int32), ("a_rep", C.c_int32)]
+
+
+class ConvArgs(C.Structure):
+    """Mirror of ``vk_conv_args`` (field order and types must match the header)."""
+    _fields_ = [
+        ("x", _fp), ("x_bstride", C.c_int64), ("x_cstride", C.c_int64),
+        ("w", _fp),
+        ("bias", _fp), ("bias_bstride", C.c_int64),
+        ("out", _fp), ("out_bstride", C.c_int64), ("out_cstride", C.c_int64),
+        ("res", _fp), ("res_bstride", C.c_int64), ("res_cstride", C.c_int64),
+        ("out2", _fp), ("out2_bstride", C.c_int64), ("out2_cstride", C.c_int64),
+        ("out3", _fp), ("aux", _fp),
+        ("mask", _fp),
+        ("batch", C.c_int32), ("c_in", C.c_int32), ("c_out", C.c_int32), ("length", C.c_int32),
+        ("taps", C.c_int32), ("dilation", C.c_int32), ("pad", C.c_int32),
+        ("tile", C.c_int32), ("epilogue", C.c_int32),
+        ("act_in", C.c_int32), ("in_slope", C.c_float),
+        ("first", C.c_int32), ("hidden", C.c_int32), ("up_stride", C.c_int32),
+        ("navg", C.c_float),
+    ]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} not found: run `python -m vits_amd.build` "
+                              "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(LIB_PATH)
+        L.vk_abi_version.restype = C.c_int
+        L.vk_last_error.restype = C.c_char_p
+        L.vk_tile_query.argtypes = [C.c_int, C.POINTER(TileInfo)]
+        L.vk_conv1d.argtypes = [C.POINTER(ConvArgs), C.c_void_p]
+        L.vk_conv1d_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
+        L.vk_conv1d_lds_bytes.restype = C.c_int64
+        L.vk_speaker_linear.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.vk_post_conv_tanh.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.c_void_p]
+        if L.vk_abi_version() != 1:
+            raise NativeError("libvits_amd.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise NativeError(f"{what} failed ({rc}): {lib().vk_last_error().decode()}")
+
+
+_tile_cache = {}
+
+
+def tile_info(tile: int) -> TileInfo:
+    if tile not in _tile_cache:
+        ti = TileInfo()
+        check(lib().vk_tile_query(tile, C.byref(ti)), "vk_tile_query")
+        _tile_cache[tile] = ti
+    return _tile_cache[tile]
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _view(t: torch.Tensor):
+    """(pointer, batch stride, channel stride) of a [B, C, L] fp32 view whose time axis is dense."""
+    assert t.dtype == torch.float32 and t.dim() == 3 and (t.shape[2] == 1 or t.stride(2) == 1), \
+        (t.dtype, t.shape, t.stride())
+    return t.data_ptr(), t.stride(0), t.stride(1)
+
+
+def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue,
+           bias=None, bias_bstride=0, res=None, out2=None, out3=None, aux=None, mask=None,
+           act_in=False, in_slope=1.0, first=False, hidden=0, up_stride=0, navg=1.0):
+    """Enqueue one fused convolution on the current stream of ``x``'s device."""
+    assert x.is_cuda, "the HIP path needs device tensors"
+    a = ConvArgs()
+    a.x, a.x_bstride, a.x_cstride = _view(x)
+    a.w = w_packed.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.bias_bstride = bias_bstride
+    a.out, a.out_bstride, a.out_cstride = _view(out)
+    if res is not None:
+        a.res, a.res_bstride, a.res_cstride = _view(res)
+    if out2 is not None:
+        a.out2, a.out2_bstride, a.out2_cstride = _view(out2)
+    if out3 is not None:
+        p3, b3, c3 = _view(out3)
+        assert (b3, c3) == (a.out_bstride, a.out_cstride)
+        a.out3 = p3
+    if aux is not None:
+        pa, ba, ca = _view(aux)
+        assert (ba, ca) == (a.out_bstride, a.out_cstride)
+        a.aux = pa
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.is_contiguous()
+        a.mask = mask.data_ptr()
+    a.batch, a.c_in, a.c_out, a.length = x.shape[0], c_in, c_out, x.shape[2]
+    a.taps, a.dilation, a.pad = taps, dilation, pad
+    a.tile, a.epilogue = tile, epilogue
+    a.act_in, a.in_slope = int(act_in), in_slope
+    a.first, a.hidden, a.up_stride, a.navg = int(first), hidden, up_stride, navg
+    check(lib().vk_conv1d(C.byref(a), stream_ptr(x.device)), "vk_conv1d")
+
+
+def speaker_linear(g, w, bias, out):
+    """out[b, :] = w @ g[b, :] + bias for g [B, n_in], w [n_out, n_in]."""
+    assert g.is_cuda and g.is_contiguous() and w.is_contiguous() and out.is_contiguous()
+    check(lib().vk_speaker_linear(g.data_ptr(), w.data_ptr(),
+                                  bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                  g.shape[0], w.shape[1], w.shape[0], stream_ptr(g.device)),
+          "vk_speaker_linear")
+
+
+def post_conv_tanh(x, w, wav, slope):
+    assert x.is_cuda and x.is_contiguous() and w.is_contiguous() and wav.is_contiguous()
+    check(lib().vk_post_conv_tanh(x.data_ptr(), w.data_ptr(), wav.data_ptr(), x.shape[0], x.shape[1],
+                                  x.shape[2], w.shape[-1], slope, stream_ptr(x.device)),
+          "vk_post_conv_tanh")

@@ -1,0 +1,78 @@
+"""Host-side weight preparation: weight-norm folding and MFMA fragment packing.
+
+The reference recomputes ``w = g * v / ||v||`` in a forward pre-hook on every call
+(old-style ``nn.utils.weight_norm``: decoder.py:27-42,96 and wn.py:42,50,58 under
+/root/reference/module/model_component).  Here it is folded once when the weights are
+bound, together with a re-layout into the order the convolution kernel's wavefronts
+consume (csrc/conv_mfma.hpp):
+
+    packed[mt][chunk][tap][g][lane][e] = W[row(32*mt + (lane & 31)), chunk*CK + 2*(4*g + e) + (lane >> 5), tap]
+
+i.e. for each 32-row tile ``mt`` a linear stream of 64-lane x float4 groups; one group
+feeds four consecutive k-steps (channel pairs) of v_mfma_f32_32x32x2_f32.  Rows are
+zero-padded to the tile family's rows-per-workgroup and channels to its chunk size; one
+spare zero group at the very end absorbs the kernel's one-group-ahead prefetch.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def fold_weight_norm(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """w = g * v / ||v|| with the norm over every axis but 0 (ConvTranspose1d included:
+    there axis 0 is the input channel)."""
+    return torch._weight_norm(v, g, 0)
+
+
+def pack_conv_weight(w: torch.Tensor, ck: int, rows_per_block: int, row_order=None) -> torch.Tensor:
+    """w [rows, c_in, taps] -> flat fp32 tensor in fragment order.
+
+    ``row_order``: optional 1-D index tensor giving, for each packed row, the source row
+    of ``w`` (used to interleave paired row tiles)."""
+    w = w.detach().to(torch.float32)
+    if row_order is not None:
+        w = w[row_order]
+    rows, cin, taps = w.shape
+    rpad = -(-rows // rows_per_block) * rows_per_block
+    cpad = -(-cin // ck) * ck
+    wp = torch.zeros(rpad, cpad, taps, dtype=torch.float32, device=w.device)
+    wp[:rows, :cin] = w
+    mt, nch, g = rpad // 32, cpad // ck, ck // 8
+    # [mt, r, chunk, g, e, h, tap] -> [mt, chunk, tap, g, h, r, e]
+    wp = wp.view(mt, 32, nch, g, 4, 2, taps).permute(0, 2, 6, 3, 5, 1, 4).contiguous()
+    flat = wp.view(-1)
+    return torch.cat([flat, torch.zeros(256, dtype=torch.float32, device=w.device)])
+
+
+def pair_row_order(hidden: int) -> torch.Tensor:
+    """Row order that interleaves 32-row tiles of the two halves of a 2*hidden-row output:
+    [a0, b0, a1, b1, ...] with a_q = rows 32q.., b_q = rows hidden + 32q.."""
+    assert hidden % 32 == 0
+    idx = []
+    for q in range(hidden // 32):
+        idx += list(range(32 * q, 32 * q + 32))
+        idx += list(range(hidden + 32 * q, hidden + 32 * q + 32))
+    return torch.tensor(idx, dtype=torch.int64)
+
+
+def transposed_to_polyphase(wt: torch.Tensor, stride: int) -> torch.Tensor:
+    """ConvTranspose1d weight [c_in, c_out, 2*stride] (padding stride/2) -> the weight of an
+    equivalent 2-tap convolution with stride*c_out output rows, row = phase*c_out + channel.
+
+    Output sample o = stride*t + p receives, per input channel,
+        p <  stride/2:  w[.., p + stride/2 + stride] * x[t-1] + w[.., p + stride/2] * x[t]
+        p >= stride/2:  w[.., p + stride/2] * x[t]            + w[.., p - stride/2] * x[t+1]
+    (from o = i*stride - stride/2 + k of nn.ConvTranspose1d, decoder.py:96-97), so tap j of
+    phase p reads x[t + j - 1] for the lower phases and x[t + j] for the upper ones."""
+    cin, cout, k = wt.shape
+    assert k == 2 * stride and stride % 2 == 0
+    hs = stride // 2
+    out = torch.empty(stride, cout, cin, 2, dtype=wt.dtype, device=wt.device)
+    for p in range(stride):
+        if p < hs:
+            k0, k1 = p + hs + stride, p + hs
+        else:
+            k0, k1 = p + hs, p - hs
+        out[p, :, :, 0] = wt[:, :, k0].t()
+        out[p, :, :, 1] = wt[:, :, k1].t()
+    return out.reshape(stride * cout, cin, 2)
