@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Benchmark of the VITS generator hot path on MI355X: reverse flow + HiFi-GAN decoder.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" is one pass of the hot path (flow reverse -> decoder) over one batch of
+synthetic latents already resident in HBM: 16 utterances x 862 frames (10.008 s each at
+22050 Hz), 16 seeded speakers out of 100, random-init weights from vits_amd.synth.
+For N > 1 the driver starts one process per GPU (torch.distributed.run); every rank runs
+the same per-GPU batch (weak scaling, utterance-sharded, no collective in the hot path)
+and RCCL is used only for the barrier and the max-over-ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line: audio seconds generated per wall second (whole job), a
+roofline object for the kernel family that took the most device time (algorithmic FLOPs
+of its launches / their summed device time from per-launch events on the launch stream),
+and - at N = 1 - the CPU oracle timed on this host's cores on one 10 s utterance.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vits_amd import native, synth                                   # noqa: E402
+from vits_amd.module.vits_generator import HotPathGenerator          # noqa: E402
+
+SAMPLE_RATE = 22050
+HOP = 256
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+SEED = 999
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--frames", type=int, default=862, help="latent frames per utterance (862 = 10 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, frames: int, budget_s: float):
+    """The CPU oracle (stock PyTorch CPU ops, the kernels the reference dispatches to) on one
+    utterance of the same length, repeated for about ``budget_s`` seconds."""
+    from oracle import vits_oracle as O
+    z = synth.latent(SEED, "bench.cpu.z", 1, frames)
+    mask = synth.length_mask([frames], frames)
+    g = O.speaker_embed(torch.tensor([9]), sd)
+    with torch.no_grad():
+        O.flow_reverse_decode(z, mask, g, sd)                     # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.flow_reverse_decode(z, mask, g, sd)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 100:
+                break
+    audio = n * frames * HOP / SAMPLE_RATE
+    return {"value": audio / el, "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x (1 utterance x {frames} frames = {frames * HOP / SAMPLE_RATE:.2f} s): "
+                      f"flow-reverse + decoder, fp32, {el:.1f} s of CPU time"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    torch.set_grad_enabled(False)
+    sd = synth.hot_path_state_dict(SEED, with_posterior=False)
+    gen = HotPathGenerator(100, with_posterior=False)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(dev).eval()
+
+    B, T = args.batch, args.frames
+    key = f"bench.rank{rank}"
+    z_p = synth.latent(SEED, key, B, T).to(dev)
+    lengths = torch.full((B,), T, dtype=torch.int64)
+    mask = synth.length_mask(lengths, T).to(dev)
+    ids = synth.speaker_ids(SEED, key, B).to(dev)
+
+    def step():
+        g = gen.embed_speaker(ids)
+        return gen.flow_reverse_decode(z_p, mask, g)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        wav = step()
+    fence()
+    timer = native.LaunchTimer()
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(args.steps):
+            wav = step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert wav.shape == (B, 1, T * HOP) and bool(torch.isfinite(wav).all())
+
+    audio_per_step = float(lengths.sum().item()) * HOP / SAMPLE_RATE
+    value = world * audio_per_step * args.steps / elapsed
+
+    if rank == 0:
+        fam = timer.summary()
+        name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        total_ms = sum(d["ms"] for d in fam.values())
+        total_flops = sum(d["flops"] for d in fam.values())
+        line = {
+            "metric": "audio seconds generated/sec (RTF^-1), 10 s utterances",
+            "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "reverse flow + HiFi-GAN decoder (TTS hot path), "
+                                   f"batch {B} x {T} frames ({T * HOP / SAMPLE_RATE:.2f} s) per GPU, 100 speakers, "
+                                   "random-init weights",
+                       "batch_per_gpu": B, "frames": T, "sample_rate": SAMPLE_RATE,
+                       "parallelism": f"utterance-sharded x{world}, no hot-path collective"},
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                         "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                         "share_of_device_time": dom["ms"] / total_ms,
+                         "all_kernels_tflops": total_flops / (total_ms * 1e-3) / 1e12},
+            "per_gpu_value": value / world,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(synth.hot_path_state_dict(SEED, with_posterior=False),
+                                                T, args.cpu_seconds)
+        if os.environ.get("BENCH_VERBOSE"):
+            for k, d in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"# {k:44s} n={d['launches']:5d} ms={d['ms']:9.2f} "
+                      f"TF={d['flops'] / max(d['ms'], 1e-9) / 1e9:7.2f}", file=sys.stderr)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

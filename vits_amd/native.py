@@ -102,6 +102,54 @@ def _view(t: torch.Tensor):
     return t.data_ptr(), t.stride(0), t.stride(1)
 
 
+class LaunchTimer:
+    """While active, every kernel launch made through this module is bracketed by a pair of
+    events on the launch stream and tagged with its kernel family and algorithmic FLOPs, so
+    a benchmark can attribute device time per kernel without an external profiler."""
+
+    active = None
+
+    def __init__(self):
+        self.records = []          # (family, flops, bytes, start_event, end_event)
+
+    def __enter__(self):
+        LaunchTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        LaunchTimer.active = None
+
+    def summary(self):
+        """family -> dict(launches, ms, flops, bytes); call after a device synchronize."""
+        out = {}
+        for fam, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+def _timed(family, flops, nbytes, device, launch):
+    t = LaunchTimer.active
+    if t is None:
+        return launch()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    s = torch.cuda.current_stream(device)
+    e0.record(s)
+    rc = launch()
+    e1.record(s)
+    t.records.append((family, flops, nbytes, e0, e1))
+    return rc
+
+
+_EPI_NAMES = ["store", "resid", "resid_acc", "resid_avg", "gate", "wn_mid", "wn_last",
+              "couple_rev", "couple_fwd", "upsample", "sample"]
+_TILE_NAMES = ["m128", "m64", "m32", "pair"]
+
+
 def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue,
            bias=None, bias_bstride=0, res=None, out2=None, out3=None, aux=None, mask=None,
            act_in=False, in_slope=1.0, first=False, hidden=0, up_stride=0, navg=1.0):
@@ -133,20 +181,31 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     a.tile, a.epilogue = tile, epilogue
     a.act_in, a.in_slope = int(act_in), in_slope
     a.first, a.hidden, a.up_stride, a.navg = int(first), hidden, up_stride, navg
-    check(lib().vk_conv1d(C.byref(a), stream_ptr(x.device)), "vk_conv1d")
+    rows = c_out * up_stride if epilogue == EPI_UPSAMPLE else c_out
+    flops = 2.0 * x.shape[0] * x.shape[2] * rows * c_in * taps
+    family = f"conv_mfma[{_TILE_NAMES[tile]},{_EPI_NAMES[epilogue]},act={int(act_in)}]"
+    L = lib()
+    sp = stream_ptr(x.device)
+    check(_timed(family, flops, 0.0, x.device, lambda: L.vk_conv1d(C.byref(a), sp)), "vk_conv1d")
 
 
 def speaker_linear(g, w, bias, out):
     """out[b, :] = w @ g[b, :] + bias for g [B, n_in], w [n_out, n_in]."""
     assert g.is_cuda and g.is_contiguous() and w.is_contiguous() and out.is_contiguous()
-    check(lib().vk_speaker_linear(g.data_ptr(), w.data_ptr(),
-                                  bias.data_ptr() if bias is not None else None, out.data_ptr(),
-                                  g.shape[0], w.shape[1], w.shape[0], stream_ptr(g.device)),
+    L, sp = lib(), stream_ptr(g.device)
+    flops = 2.0 * g.shape[0] * w.shape[0] * w.shape[1]
+    check(_timed("speaker_linear", flops, 4.0 * w.numel(), g.device,
+                 lambda: L.vk_speaker_linear(g.data_ptr(), w.data_ptr(),
+                                             bias.data_ptr() if bias is not None else None,
+                                             out.data_ptr(), g.shape[0], w.shape[1], w.shape[0], sp)),
           "vk_speaker_linear")
 
 
 def post_conv_tanh(x, w, wav, slope):
     assert x.is_cuda and x.is_contiguous() and w.is_contiguous() and wav.is_contiguous()
-    check(lib().vk_post_conv_tanh(x.data_ptr(), w.data_ptr(), wav.data_ptr(), x.shape[0], x.shape[1],
-                                  x.shape[2], w.shape[-1], slope, stream_ptr(x.device)),
+    L, sp = lib(), stream_ptr(x.device)
+    flops = 2.0 * x.numel() * w.shape[-1]
+    check(_timed("post_conv_tanh", flops, 4.0 * (x.numel() + wav.numel()), x.device,
+                 lambda: L.vk_post_conv_tanh(x.data_ptr(), w.data_ptr(), wav.data_ptr(), x.shape[0],
+                                             x.shape[1], x.shape[2], w.shape[-1], slope, sp)),
           "vk_post_conv_tanh")
