@@ -160,6 +160,11 @@ def main():
             for k, d in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
                 print(f"# {k:44s} n={d['launches']:5d} ms={d['ms']:9.2f} "
                       f"TF={d['flops'] / max(d['ms'], 1e-9) / 1e9:7.2f}", file=sys.stderr)
+            if os.environ.get("BENCH_VERBOSE") == "2":
+                per = len(timer.records) // args.steps
+                for fam_, fl, _, e0, e1, det in timer.records[-per:]:
+                    ms = e0.elapsed_time(e1)
+                    print(f"## {fam_:40s} {det:32s} ms={ms:8.3f} TF={fl / max(ms, 1e-9) / 1e9:7.2f}", file=sys.stderr)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

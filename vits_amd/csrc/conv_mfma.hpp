@@ -162,12 +162,162 @@ conv_mfma_kernel(const ConvDev d)
     }
 
     // ---------------------------------- epilogue ----------------------------------------
+    // Interior tiles (every row and column of the wave's tile in range) take a branch-free
+    // path: wave-uniform row pointers plus one per-lane offset, the epilogue's loads issued
+    // sixteen at a time ahead of the arithmetic.  Edge tiles take the predicated path below.
     const int tw = t0 + wn * TNW + l31;                 // this lane's time for n = 0
     const int64_t ob  = (int64_t)b * p.out_bstride;
     const int64_t rb  = (int64_t)b * p.res_bstride;
     const int64_t o2b = (int64_t)b * p.out2_bstride;
     const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
+    const int rows_total = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
+    const bool interior = (t0 + wn * TNW + TNW <= L) && ((mt0 + A_REP) * 32 <= rows_total);
 
+    if (interior) {
+        const float* maskb = p.mask ? p.mask + (int64_t)b * L : nullptr;
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int m = 0; m < A_REP; m += 2) {
+                const int R0 = 16 * (mt0 + m);            // first output row of the pair (32 * q)
+                float ba[16], bb[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ba[r] = 0.0f; bb[r] = 0.0f; }
+                if (biasb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = R0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        ba[r] = biasb[row];
+                        bb[r] = biasb[p.hidden + row];
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n) {
+                    const int t = tw + 32 * n;
+                    const float mkv = maskb ? maskb[t] : 1.0f;
+                    float ev[16];
+                    if constexpr (EPI == VK_EPI_SAMPLE) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float* ap = p.aux + ob + (int64_t)(R0 + (r & 3) + 8 * (r >> 2)) * p.out_cstride;
+                            ev[r] = ap[4 * half * p.out_cstride + t];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = R0 + (r & 3) + 8 * (r >> 2);
+                        const int loff = 4 * half * (int)p.out_cstride + t;
+                        const float va = acc[m][n][r] + ba[r];
+                        const float vb = acc[m + 1][n][r] + bb[r];
+                        float* op = p.out + ob + (int64_t)rr * p.out_cstride;
+                        if constexpr (EPI == VK_EPI_GATE) {
+                            op[loff] = tanhf(va) * vk_sigmoid(vb);
+                        } else {
+                            const float mean = va * mkv, logs = vb * mkv;
+                            op[loff] = mean;
+                            (p.out3 + ob + (int64_t)rr * p.out_cstride)[loff] = logs;
+                            (p.out2 + o2b + (int64_t)rr * p.out2_cstride)[4 * half * (int)p.out2_cstride + t] =
+                                (mean + ev[r] * expf(logs)) * mkv;
+                        }
+                    }
+                }
+            }
+        } else if constexpr (EPI == VK_EPI_UPSAMPLE) {
+            const int S = p.up_stride;
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m) {
+                const int prow0 = (mt0 + m) * 32;
+                const int phase = prow0 / p.c_out;
+                const int co0 = prow0 - phase * p.c_out;
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
+                if (biasb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bv[r] = biasb[co0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                }
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n) {
+                    const int loff = 4 * half * (int)p.out_cstride + (tw + 32 * n) * S + phase;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* op = p.out + ob + (int64_t)(co0 + (r & 3) + 8 * (r >> 2)) * p.out_cstride;
+                        op[loff] = acc[m][n][r] + bv[r];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m) {
+                const int R0 = (mt0 + m) * 32;
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
+                if (biasb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bv[r] = biasb[R0 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                }
+                const bool skip_half = (EPI == VK_EPI_WN_MID) && (R0 >= p.hidden);     // wave-uniform
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n) {
+                    const int t = tw + 32 * n;
+                    const float mkv = maskb ? maskb[t] : 1.0f;
+                    const int olo  = 4 * half * (int)p.out_cstride + t;
+                    const int rlo  = 4 * half * (int)p.res_cstride + t;
+                    const int o2lo = 4 * half * (int)p.out2_cstride + t;
+                    float rv[16], sv[16];
+                    constexpr bool NEED_RES = (EPI == VK_EPI_RESID || EPI == VK_EPI_RESID_ACC || EPI == VK_EPI_RESID_AVG ||
+                                               EPI == VK_EPI_WN_MID || EPI == VK_EPI_COUPLE_REV || EPI == VK_EPI_COUPLE_FWD);
+                    constexpr bool NEED_ACC = (EPI == VK_EPI_RESID_ACC || EPI == VK_EPI_RESID_AVG ||
+                                               EPI == VK_EPI_WN_MID || EPI == VK_EPI_WN_LAST);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = R0 + (r & 3) + 8 * (r >> 2);
+                        rv[r] = 0.0f; sv[r] = 0.0f;
+                        if constexpr (NEED_RES) {
+                            if (!skip_half) rv[r] = (p.res + rb + (int64_t)rr * p.res_cstride)[rlo];
+                        }
+                        if constexpr (NEED_ACC) {
+                            if constexpr (EPI == VK_EPI_WN_MID) {
+                                if (skip_half && !p.first)
+                                    sv[r] = (p.out2 + o2b + (int64_t)(rr - p.hidden) * p.out2_cstride)[o2lo];
+                            } else if constexpr (EPI == VK_EPI_WN_LAST) {
+                                if (!p.first) sv[r] = (p.out2 + o2b + (int64_t)rr * p.out2_cstride)[o2lo];
+                            } else {
+                                sv[r] = (p.out2 + o2b + (int64_t)rr * p.out2_cstride)[o2lo];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = R0 + (r & 3) + 8 * (r >> 2);
+                        const float v = acc[m][n][r] + bv[r];
+                        float* op = p.out + ob + (int64_t)rr * p.out_cstride;
+                        if constexpr (EPI == VK_EPI_STORE) {
+                            op[olo] = v * mkv;
+                        } else if constexpr (EPI == VK_EPI_RESID) {
+                            op[olo] = v + rv[r];
+                        } else if constexpr (EPI == VK_EPI_RESID_ACC) {
+                            op[olo] = sv[r] + (v + rv[r]);
+                        } else if constexpr (EPI == VK_EPI_RESID_AVG) {
+                            op[olo] = (sv[r] + (v + rv[r])) / p.navg;
+                        } else if constexpr (EPI == VK_EPI_WN_MID) {
+                            if (!skip_half) op[olo] = (rv[r] + v) * mkv;
+                            else (p.out2 + o2b + (int64_t)(rr - p.hidden) * p.out2_cstride)[o2lo] = sv[r] + v;
+                        } else if constexpr (EPI == VK_EPI_WN_LAST) {
+                            op[olo] = (sv[r] + v) * mkv;
+                        } else if constexpr (EPI == VK_EPI_COUPLE_REV) {
+                            op[olo] = (rv[r] - v * mkv) * mkv;
+                        } else if constexpr (EPI == VK_EPI_COUPLE_FWD) {
+                            op[olo] = v * mkv + rv[r] * mkv;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- edge tiles: per-element predication ----
     float mk[B_REP];
 #pragma unroll
     for (int n = 0; n < B_REP; ++n) {

@@ -110,7 +110,7 @@ class LaunchTimer:
     active = None
 
     def __init__(self):
-        self.records = []          # (family, flops, bytes, start_event, end_event)
+        self.records = []          # (family, flops, bytes, start_event, end_event, detail)
 
     def __enter__(self):
         LaunchTimer.active = self
@@ -122,7 +122,7 @@ class LaunchTimer:
     def summary(self):
         """family -> dict(launches, ms, flops, bytes); call after a device synchronize."""
         out = {}
-        for fam, flops, nbytes, e0, e1 in self.records:
+        for fam, flops, nbytes, e0, e1, _ in self.records:
             d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -131,7 +131,7 @@ class LaunchTimer:
         return out
 
 
-def _timed(family, flops, nbytes, device, launch):
+def _timed(family, flops, nbytes, device, launch, detail=""):
     t = LaunchTimer.active
     if t is None:
         return launch()
@@ -141,7 +141,7 @@ def _timed(family, flops, nbytes, device, launch):
     e0.record(s)
     rc = launch()
     e1.record(s)
-    t.records.append((family, flops, nbytes, e0, e1))
+    t.records.append((family, flops, nbytes, e0, e1, detail))
     return rc
 
 
@@ -186,7 +186,8 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     family = f"conv_mfma[{_TILE_NAMES[tile]},{_EPI_NAMES[epilogue]},act={int(act_in)}]"
     L = lib()
     sp = stream_ptr(x.device)
-    check(_timed(family, flops, 0.0, x.device, lambda: L.vk_conv1d(C.byref(a), sp)), "vk_conv1d")
+    detail = f"B{x.shape[0]} L{x.shape[2]} {c_in}->{rows} k{taps} d{dilation}"
+    check(_timed(family, flops, 0.0, x.device, lambda: L.vk_conv1d(C.byref(a), sp), detail), "vk_conv1d")
 
 
 def speaker_linear(g, w, bias, out):
