@@ -1,6 +1,7 @@
 // Host side of the C ABI: argument validation, tile geometry, launches.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "conv_launch.hpp"
 #include "api_internal.hpp"
@@ -81,6 +82,8 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds)
     d->xw = TN + halo;
     d->lds_stride = d->xw;
     d->groups_per_mt = d->nchunk * a->taps * (G.ck / 8);
+    static const int dbg = getenv("VK_DEBUG_SKIP") ? atoi(getenv("VK_DEBUG_SKIP")) : 0;
+    d->dbg = dbg;
     const int rows_blk = 32 * G.a_rep * G.wm;
     const int64_t rows = gemm_rows(a);
     *grid = dim3((unsigned)((a->length + TN - 1) / TN), (unsigned)((rows + rows_blk - 1) / rows_blk), (unsigned)a->batch);

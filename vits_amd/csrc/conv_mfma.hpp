@@ -30,6 +30,7 @@ struct ConvDev {
     int xw;             // staged columns per row: time tile + halo
     int lds_stride;     // floats between staged rows
     int groups_per_mt;  // 64-lane x float4 groups per 32-row tile: nchunk * taps * CK / 8
+    int dbg;            // timing experiments only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop
 };
 
 __device__ __forceinline__ float vk_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -68,18 +69,25 @@ conv_mfma_kernel(const ConvDev d)
     const float* xb = p.x + (int64_t)b * p.x_bstride;
 
     // ---- staging: global -> registers (issued early) -> LDS (written after the barrier) ----
+    // Column j*64 + lane of the staged tile is time ts + j*64 + lane for every row and chunk,
+    // so the clamped load offsets and the in-range bits are computed once.
+    int toff[NJ];
+    unsigned inrange = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int t = ts + lane + 64 * j;
+        toff[j] = t < 0 ? 0 : (t >= L ? L - 1 : t);
+        if (t >= 0 && t < L) inrange |= 1u << j;
+    }
+    const bool last_col_ok = (lane + 64 * (NJ - 1)) < d.xw;      // only the last piece can overhang
     float stage[RPW][NJ];
     auto issue_loads = [&](int chunk) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const int c = chunk * CK + w + r * NW;
+            const int c = chunk * CK + w + r * NW;                        // wave-uniform
             const float* row = xb + (int64_t)(c < p.c_in ? c : 0) * p.x_cstride;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                int t = ts + lane + 64 * j;
-                t = t < 0 ? 0 : (t >= L ? L - 1 : t);      // clamp: the select happens at store time
-                stage[r][j] = row[t];
-            }
+            for (int j = 0; j < NJ; ++j) stage[r][j] = row[toff[j]];      // the select happens at store time
         }
     };
     auto store_chunk = [&](int chunk, float* buf) {
@@ -87,13 +95,12 @@ conv_mfma_kernel(const ConvDev d)
         for (int r = 0; r < RPW; ++r) {
             const int cl = w + r * NW;
             const bool cok = (chunk * CK + cl) < p.c_in;
+            float* dst = buf + cl * stride + lane;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int col = lane + 64 * j;
-                const int t = ts + col;
-                float v = (cok && t >= 0 && t < L) ? stage[r][j] : 0.0f;
+                float v = (cok && ((inrange >> j) & 1u)) ? stage[r][j] : 0.0f;
                 if (ACT) v = v > 0.0f ? v : v * p.in_slope;
-                if (col < d.xw) buf[cl * stride + col] = v;
+                if (j < NJ - 1 || last_col_ok) dst[64 * j] = v;
             }
         }
     };
@@ -119,10 +126,15 @@ conv_mfma_kernel(const ConvDev d)
         shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
     }
     const int bcol = half * stride + wn * TNW + l31 + shift;
-
-    float4 a_next[A_REP];
+    
+    // Weight fragments are fetched one whole tap (GPC groups) ahead: the loads for tap+1 are
+    // issued when tap starts and first touched when it ends, so a full tap of MFMAs covers
+    // them, and the in-order memory counter gives the chunk's staging loads the same cover.
+    float4 a[GPC][A_REP];
 #pragma unroll
-    for (int m = 0; m < A_REP; ++m) a_next[m] = *aptr[m];
+    for (int g = 0; g < GPC; ++g)
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) a[g][m] = aptr[m][64 * g];
 
     issue_loads(0);
     for (int chunk = 0; chunk < d.nchunk; ++chunk) {
@@ -130,24 +142,35 @@ conv_mfma_kernel(const ConvDev d)
         store_chunk(chunk, buf);
         __syncthreads();
         if (chunk + 1 < d.nchunk) issue_loads(chunk + 1);
+        if (d.dbg & 2) continue;
 
+        // k-steps walk channel pairs within a tap, then taps; the B fragments of the next
+        // k-step are read from LDS before the current k-step's MFMAs are issued.
+        const float* bk = buf + bcol;
+        float bf[B_REP];
+#pragma unroll
+        for (int n = 0; n < B_REP; ++n) bf[n] = bk[32 * n];
+#pragma unroll 1
         for (int tap = 0; tap < p.taps; ++tap) {
-            const float* bt = buf + bcol + tap * p.dilation;
+            const float* next_tap = (tap + 1 < p.taps) ? buf + bcol + (tap + 1) * p.dilation
+                                                       : buf + bcol;      // chunk end: harmless re-read
+            float4 a_nxt[GPC][A_REP];
+#pragma unroll
+            for (int g = 0; g < GPC; ++g)
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a_nxt[g][m] = aptr[m][64 * (GPC + g)];
+            __builtin_amdgcn_sched_group_barrier(0x020, GPC * A_REP, 0);
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
                 float4 a_cur[A_REP];
 #pragma unroll
-                for (int m = 0; m < A_REP; ++m) {
-                    a_cur[m] = a_next[m];
-                    aptr[m] += 64;
-                    a_next[m] = *aptr[m];          // packed buffer carries one spare group at its end
-                }
+                for (int m = 0; m < A_REP; ++m) a_cur[m] = a[g][m];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float* bk = bt + (2 * (4 * g + e)) * stride;
-                    float bf[B_REP];
+                    const float* nk = (g == GPC - 1 && e == 3) ? next_tap : bk + 2 * stride;
+                    float bn[B_REP];
 #pragma unroll
-                    for (int n = 0; n < B_REP; ++n) bf[n] = bk[32 * n];
+                    for (int n = 0; n < B_REP; ++n) bn[n] = nk[32 * n];
 #pragma unroll
                     for (int m = 0; m < A_REP; ++m) {
                         const float av = (e == 0) ? a_cur[m].x : (e == 1) ? a_cur[m].y
@@ -156,8 +179,19 @@ conv_mfma_kernel(const ConvDev d)
                         for (int n = 0; n < B_REP; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc[m][n], 0, 0, 0);
                     }
+#pragma unroll
+                    for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
+                    bk = nk;
+                    __builtin_amdgcn_sched_group_barrier(0x100, (B_REP + 1) / 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, A_REP * B_REP, 0);
                 }
             }
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * GPC;
+#pragma unroll
+            for (int g = 0; g < GPC; ++g)
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a[g][m] = a_nxt[g][m];
         }
     }
 
@@ -172,6 +206,7 @@ conv_mfma_kernel(const ConvDev d)
     const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
     const int rows_total = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
     const bool interior = (t0 + wn * TNW + TNW <= L) && ((mt0 + A_REP) * 32 <= rows_total);
+    if ((d.dbg & 1) && acc[0][0][0] != 12345.678f) return;
 
     if (interior) {
         const float* maskb = p.mask ? p.mask + (int64_t)b * L : nullptr;

@@ -10,8 +10,8 @@ consume (csrc/conv_mfma.hpp):
 
 i.e. for each 32-row tile ``mt`` a linear stream of 64-lane x float4 groups; one group
 feeds four consecutive k-steps (channel pairs) of v_mfma_f32_32x32x2_f32.  Rows are
-zero-padded to the tile family's rows-per-workgroup and channels to its chunk size; one
-spare zero group at the very end absorbs the kernel's one-group-ahead prefetch.
+zero-padded to the tile family's rows-per-workgroup and channels to its chunk size; spare
+zero groups at the very end absorb the kernel's one-tap-ahead prefetch.
 """
 from __future__ import annotations
 
@@ -41,7 +41,7 @@ def pack_conv_weight(w: torch.Tensor, ck: int, rows_per_block: int, row_order=No
     # [mt, r, chunk, g, e, h, tap] -> [mt, chunk, tap, g, h, r, e]
     wp = wp.view(mt, 32, nch, g, 4, 2, taps).permute(0, 2, 6, 3, 5, 1, 4).contiguous()
     flat = wp.view(-1)
-    return torch.cat([flat, torch.zeros(256, dtype=torch.float32, device=w.device)])
+    return torch.cat([flat, torch.zeros(4 * 256, dtype=torch.float32, device=w.device)])
 
 
 def pair_row_order(hidden: int) -> torch.Tensor:
