@@ -14,6 +14,10 @@ int vk_fail(int code, const char* msg)
     return code;
 }
 
+static unsigned long long* g_stamps = nullptr;
+// Diagnostic only (not part of the public header): per-workgroup time stamps of later launches.
+extern "C" void vk_debug_set_stamps(void* dev_buffer) { g_stamps = (unsigned long long*)dev_buffer; }
+
 extern "C" int vk_abi_version(void) { return VK_ABI_VERSION; }
 extern "C" const char* vk_last_error(void) { return g_err; }
 
@@ -84,10 +88,13 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds)
     d->groups_per_mt = d->nchunk * a->taps * (G.ck / 8);
     static const int dbg = getenv("VK_DEBUG_SKIP") ? atoi(getenv("VK_DEBUG_SKIP")) : 0;
     d->dbg = dbg;
+    d->stamps = g_stamps;
     const int rows_blk = 32 * G.a_rep * G.wm;
     const int64_t rows = gemm_rows(a);
     *grid = dim3((unsigned)((a->length + TN - 1) / TN), (unsigned)((rows + rows_blk - 1) / rows_blk), (unsigned)a->batch);
     *lds = (size_t)2 * G.ck * d->lds_stride * sizeof(float);
+    static const int lds_min = getenv("VK_LDS_MIN") ? atoi(getenv("VK_LDS_MIN")) : 0;   // occupancy experiments
+    if ((int)*lds < lds_min) *lds = lds_min;
     if (*lds > 160 * 1024) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: LDS tile exceeds 160 KiB");
     return VK_OK;
 }

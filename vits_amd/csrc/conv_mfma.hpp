@@ -30,10 +30,23 @@ struct ConvDev {
     int xw;             // staged columns per row: time tile + halo
     int lds_stride;     // floats between staged rows
     int groups_per_mt;  // 64-lane x float4 groups per 32-row tile: nchunk * taps * CK / 8
-    int dbg;            // timing experiments only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop
+    unsigned long long* stamps;   // diagnostic: 8 x u64 per workgroup (times, placement) or null
+    int dbg;            // timing experiments only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop,
+                        // 4 = stage only the first chunk, 8 = barrier only on the first chunk
 };
 
 __device__ __forceinline__ float vk_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// Diagnostic time stamps (100 MHz constant clock); written only when a stamp buffer is set.
+__device__ __forceinline__ void vk_stamp(const ConvDev& d, int slot)
+{
+    if (d.stamps != nullptr && threadIdx.x == 0) {
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        d.stamps[(size_t)lin * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 0) d.stamps[(size_t)lin * 8 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))
+                                                      | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+    }
+}
 
 template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT>
 __global__ void __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN)) > 0 ? (512 / (64 * WM * WN)) : 1)
@@ -67,6 +80,7 @@ conv_mfma_kernel(const ConvDev d)
     const int stride = d.lds_stride;
 
     const float* xb = p.x + (int64_t)b * p.x_bstride;
+    vk_stamp(d, 0);
 
     // ---- staging: global -> registers (issued early) -> LDS (written after the barrier) ----
     // Column j*64 + lane of the staged tile is time ts + j*64 + lane for every row and chunk,
@@ -137,11 +151,16 @@ conv_mfma_kernel(const ConvDev d)
         for (int m = 0; m < A_REP; ++m) a[g][m] = aptr[m][64 * g];
 
     issue_loads(0);
+    unsigned long long boundary_ticks = 0;      // diagnostic: time spent handing over chunks 1..n-1
     for (int chunk = 0; chunk < d.nchunk; ++chunk) {
         float* buf = lds + (chunk & 1) * (CK * stride);
-        store_chunk(chunk, buf);
-        __syncthreads();
-        if (chunk + 1 < d.nchunk) issue_loads(chunk + 1);
+        unsigned long long tb0 = 0;
+        if (d.stamps) tb0 = __builtin_amdgcn_s_memrealtime();
+        if (!(d.dbg & 4) || chunk == 0) store_chunk(chunk, buf);
+        if (!(d.dbg & 8) || chunk == 0) __syncthreads();
+        if (chunk == 0) vk_stamp(d, 1);
+        else if (d.stamps) boundary_ticks += __builtin_amdgcn_s_memrealtime() - tb0;
+        if (chunk + 1 < d.nchunk && !(d.dbg & 4)) issue_loads(chunk + 1);
         if (d.dbg & 2) continue;
 
         // k-steps walk channel pairs within a tap, then taps; the B fragments of the next
@@ -195,6 +214,9 @@ conv_mfma_kernel(const ConvDev d)
         }
     }
 
+    vk_stamp(d, 2);
+    if (d.stamps != nullptr && threadIdx.x == 0)
+        d.stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 4] = boundary_ticks;
     // ---------------------------------- epilogue ----------------------------------------
     // Interior tiles (every row and column of the wave's tile in range) take a branch-free
     // path: wave-uniform row pointers plus one per-lane offset, the epilogue's loads issued
@@ -349,6 +371,7 @@ conv_mfma_kernel(const ConvDev d)
                 }
             }
         }
+        vk_stamp(d, 3);
         return;
     }
 
