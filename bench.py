@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=862, help="latent frames per utterance (862 = 10 s)")
+    ap.add_argument("--workload", choices=["batch", "corpus"], default="batch",
+                    help="batch: fixed batch per GPU (weak scaling, the headline); corpus: a length-bucketed "
+                         "synthetic corpus sharded over the ranks (strong scaling)")
+    ap.add_argument("--corpus", type=int, default=4096, help="utterances in the corpus workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
@@ -94,14 +98,38 @@ def main():
 
     B, T = args.batch, args.frames
     key = f"bench.rank{rank}"
-    z_p = synth.latent(SEED, key, B, T).to(dev)
-    lengths = torch.full((B,), T, dtype=torch.int64)
-    mask = synth.length_mask(lengths, T).to(dev)
-    ids = synth.speaker_ids(SEED, key, B).to(dev)
+    if args.workload == "batch":
+        z_p = synth.latent(SEED, key, B, T).to(dev)
+        lengths = torch.full((B,), T, dtype=torch.int64)
+        mask = synth.length_mask(lengths, T).to(dev)
+        ids = synth.speaker_ids(SEED, key, B).to(dev)
+        out_shape = (B, 1, T * HOP)
+        valid_frames_local = float(lengths.sum().item())
 
-    def step():
-        g = gen.embed_speaker(ids)
-        return gen.flow_reverse_decode(z_p, mask, g)
+        def step():
+            g = gen.embed_speaker(ids)
+            return gen.flow_reverse_decode(z_p, mask, g)
+    else:
+        from vits_amd import sharding
+        frames, spk = sharding.synthetic_corpus(args.corpus, SEED)
+        buckets = sharding.make_buckets(frames)
+        parts, _ = sharding.assign_buckets(frames, buckets, world)
+        work = []
+        for bi in parts[rank]:
+            idx = buckets[bi]
+            lens = torch.tensor([int(frames[i]) for i in idx])
+            tmax = int(lens.max())
+            m = synth.length_mask(lens, tmax)
+            work.append((synth.latent(SEED, f"corpus.b{bi}", len(idx), tmax).mul_(m).to(dev), m.to(dev),
+                         torch.tensor([int(spk[i]) for i in idx]).to(dev)))
+        valid_frames_local = float(sum(int(frames[i]) for bi in parts[rank] for i in buckets[bi]))
+        out_shape = None
+
+        def step():
+            wav_ = None
+            for zb, mb, sb in work:
+                wav_ = gen.flow_reverse_decode(zb, mb, gen.embed_speaker(sb))
+            return wav_
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -124,10 +152,14 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert wav.shape == (B, 1, T * HOP) and bool(torch.isfinite(wav).all())
+    assert (out_shape is None or wav.shape == out_shape) and bool(torch.isfinite(wav).all())
 
-    audio_per_step = float(lengths.sum().item()) * HOP / SAMPLE_RATE
-    value = world * audio_per_step * args.steps / elapsed
+    total_frames = valid_frames_local
+    if dist is not None:
+        tf = torch.tensor([valid_frames_local], device=dev, dtype=torch.float64)
+        dist.all_reduce(tf, op=dist.ReduceOp.SUM)
+        total_frames = float(tf.item())
+    value = total_frames * HOP / SAMPLE_RATE * args.steps / elapsed
 
     if rank == 0:
         fam = timer.summary()
@@ -138,12 +170,17 @@ def main():
         line = {
             "metric": "audio seconds generated/sec (RTF^-1), 10 s utterances",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak" if args.workload == "batch" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "reverse flow + HiFi-GAN decoder (TTS hot path), "
-                                   f"batch {B} x {T} frames ({T * HOP / SAMPLE_RATE:.2f} s) per GPU, 100 speakers, "
-                                   "random-init weights",
-                       "batch_per_gpu": B, "frames": T, "sample_rate": SAMPLE_RATE,
+            "config": {"workload": ("reverse flow + HiFi-GAN decoder (TTS hot path), "
+                                    f"batch {B} x {T} frames ({T * HOP / SAMPLE_RATE:.2f} s) per GPU, 100 speakers, "
+                                    "random-init weights") if args.workload == "batch" else
+                                   ("reverse flow + HiFi-GAN decoder over a length-bucketed synthetic corpus of "
+                                    f"{args.corpus} utterances (2-15 s), sharded over the ranks, 100 speakers, "
+                                    "random-init weights"),
+                       "batch_per_gpu": B if args.workload == "batch" else None,
+                       "frames": T if args.workload == "batch" else None, "sample_rate": SAMPLE_RATE,
                        "parallelism": f"utterance-sharded x{world}, no hot-path collective"},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,

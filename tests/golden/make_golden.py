@@ -32,6 +32,11 @@ sys.dont_write_bytecode = True
 
 for _n in ("torchvision", "torchvision.models", "torchvision.transforms", "torchvision.utils"):
     sys.modules.setdefault(_n, types.ModuleType(_n))
+# module/vits_generator.py:17 imports the compiled monotonic-alignment extension (training only,
+# not built in the read-only reference tree): an inert stand-in satisfies the import.
+_mas = types.ModuleType("module.model_component.monotonic_align")
+_mas.maximum_path = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("training-only"))
+sys.modules["module.model_component.monotonic_align"] = _mas
 sys.path.insert(0, "/root/reference")
 
 from module.model_component.decoder import Decoder, ResNetBlock          # noqa: E402
@@ -39,7 +44,10 @@ from module.model_component.flow import Flow, ResidualCouplingLayer      # noqa:
 from module.model_component.wn import WN                                  # noqa: E402
 from module.model_component.posterior_encoder import PosteriorEncoder    # noqa: E402
 
+from module.vits_generator import VitsGenerator as RefGenerator           # noqa: E402
+
 from vits_amd import synth                                                # noqa: E402
+from vits_amd.module.vits_generator import VitsGenerator as OwnGenerator  # noqa: E402
 from oracle import vits_oracle as O                                       # noqa: E402
 
 SEED = 999
@@ -189,6 +197,50 @@ def main():
                         sumsq=np.float64((w10.double() ** 2).sum().item()),
                         idx=idx, samples=w10.flatten()[idx].numpy(),
                         absmax=np.float64(w10.abs().max().item()))
+    # ---- G11: complete generator: state_dict layout, front half, text_to_speech ---------------
+    import json
+    ref = RefGenerator(n_phoneme=40, n_speakers=100)
+    own = OwnGenerator(40, 100)
+    layout = [(k, list(v.shape)) for k, v in ref.state_dict().items()]
+    assert layout == [(k, list(v.shape)) for k, v in own.state_dict().items()], "state_dict layout differs"
+    with open(os.path.join(HERE, "netg_state_dict_layout.json"), "w") as f:
+        json.dump(layout, f)
+    full = synth.full_state_dict(own.state_dict(), SEED)
+    ref.load_state_dict(full, strict=True)
+    own.load_state_dict(full, strict=True)
+    ref.eval(); own.eval()
+    ids = torch.tensor([synth.TTS_SENTENCE_IDS])
+    lens = torch.tensor([ids.shape[1]])
+    spk1 = torch.tensor([9])
+    enc_ref = ref.text_encoder(ids, lens)
+    enc_own = own.text_encoder(ids, lens)
+    for name, a, b in zip(("text_encoded", "m", "logs", "mask"), enc_ref, enc_own):
+        check(f"text encoder {name}", a, b, 1e-5)
+    g1 = ref.speaker_embedding(spk1).unsqueeze(-1)
+    torch.manual_seed(4321)
+    logw_ref = ref.stochastic_duration_predictor(enc_ref[0], enc_ref[3], speaker_id_embedded=g1, reverse=True,
+                                                 noise_scale=0.8)
+    torch.manual_seed(4321)
+    noise_w = torch.randn(1, 2, ids.shape[1])
+    logw_own = own.stochastic_duration_predictor(enc_own[0], enc_own[3], speaker_id_embedded=g1, reverse=True,
+                                                 noise_scale=0.8, noise=noise_w)
+    check("duration predictor logw", logw_ref, logw_own, 1e-5)
+    LS = 3
+    torch.manual_seed(4321)
+    wav_ref = ref.text_to_speech(ids, lens, spk1, length_scale=LS)
+    T11 = wav_ref.shape[2] // 256
+    torch.manual_seed(4321)
+    noise_w = torch.randn(1, 2, ids.shape[1])
+    noise_z = torch.randn_like(torch.empty(1, T11, 192).transpose(1, 2))    # same strides as the expanded prior
+    m_p, logs_p, mask11, g11 = own.frame_prior(ids, lens, spk1, length_scale=LS, noise_w=noise_w)
+    assert m_p.shape[2] == T11, (m_p.shape, T11)
+    z11, wav11 = O.tts_tail(m_p, logs_p, mask11, noise_z, g11, full)
+    check("text_to_speech wav (own front half + oracle tail)", wav_ref, wav11, 1e-5)
+    np.savez_compressed(os.path.join(HERE, "g11_tts.npz"), ids=ids.numpy(), speaker=spk1.numpy(),
+                        length_scale=np.int64(LS), noise_w=noise_w.numpy(), noise_z=noise_z.contiguous().numpy(),
+                        text_encoded=enc_ref[0].numpy(), m=enc_ref[1].numpy(), logs=enc_ref[2].numpy(),
+                        logw=logw_ref.numpy(), wav=wav_ref.numpy())
+    print(f"  text_to_speech: {ids.shape[1]} tokens -> {T11} frames = {T11 * 256 / 22050:.2f} s")
     print("golden vectors written to", HERE)
 
 

@@ -166,3 +166,20 @@ def test_full_size_decoder_checksums(sd, golden_dir):
     np.testing.assert_allclose(wav.flatten()[torch.from_numpy(g10["idx"])].numpy(), g10["samples"], atol=GATE)
     assert abs(wav.double().sum().item() - float(g10["sum"])) < 5e-2
     assert abs((wav.double() ** 2).sum().item() - float(g10["sumsq"])) < 5e-2
+
+
+def test_text_to_speech_end_to_end(golden_dir):
+    """Whole VitsGenerator.text_to_speech on the GPU (stock-PyTorch front half + HIP hot path)
+    against the reference's waveform for the same 43-token sentence and pinned noise."""
+    from vits_amd.module.vits_generator import VitsGenerator
+    g11 = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "g11_tts.npz")).items()}
+    gen = VitsGenerator(40, 100)
+    gen.load_state_dict(synth.full_state_dict(gen.state_dict(), SEED), strict=True)
+    gen = gen.to(DEV).eval()
+    ids = g11["ids"].to(DEV)
+    wav = gen.text_to_speech(ids, torch.tensor([ids.shape[1]], device=DEV), g11["speaker"].to(DEV),
+                             length_scale=int(g11["length_scale"]), noise_w=g11["noise_w"].to(DEV),
+                             noise_z=g11["noise_z"].to(DEV))
+    assert wav.shape == g11["wav"].shape, "a duration rounded differently on the GPU front half"
+    err = _check(wav, g11["wav"], 1e-4, what="text_to_speech wav")
+    assert err <= CONTRACT

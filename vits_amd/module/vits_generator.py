@@ -14,6 +14,8 @@ import torch.nn as nn
 from .model_component.decoder import Decoder
 from .model_component.flow import Flow
 from .model_component.posterior_encoder import PosteriorEncoder
+from .model_component.stochastic_duration_predictor import StochasticDurationPredictor
+from .model_component.text_encoder import TextEncoder
 
 
 def sequence_mask(length, max_length=None):
@@ -84,3 +86,66 @@ class HotPathGenerator(nn.Module):
         z_p = self.flow(z, spec_mask, speaker_id_embedded=emb_source)
         z_hat = self.flow(z_p, spec_mask, speaker_id_embedded=emb_target, reverse=True)
         return self.decoder(z_hat * spec_mask, speaker_id_embedded=emb_target)
+
+
+class VitsGenerator(HotPathGenerator):
+    """Drop-in for the reference's ``VitsGenerator(n_phoneme, n_speakers)``
+    (/root/reference/module/vits_generator.py:67-197), inference methods only: the complete
+    ``netG_cpu.pth`` loads with ``strict=True``; ``text_to_speech`` runs the text encoder,
+    duration predictor and path expansion in stock PyTorch (:169-182) and the hot path
+    (:184-186) on the HIP kernels; ``voice_conversion`` is inherited.  The training
+    ``forward`` (:127-166) is out of scope."""
+
+    def __init__(self, n_phoneme, n_speakers):
+        nn.Module.__init__(self)
+        self.n_phoneme = n_phoneme
+        self.n_speakers = n_speakers
+        self.phoneme_embedding_dim = 192
+        self.spec_channels = 513
+        self.z_channels = 192
+        self.segment_size = 32
+        self.speaker_id_embedding_dim = 256
+        # registration order follows the reference so that state_dict() lists keys identically
+        self.text_encoder = TextEncoder(n_phoneme=n_phoneme, phoneme_embedding_dim=self.phoneme_embedding_dim,
+                                        out_channels=self.z_channels, p_dropout=0.1)
+        self.speaker_embedding = nn.Embedding(n_speakers, self.speaker_id_embedding_dim)
+        self.posterior_encoder = PosteriorEncoder(
+            speaker_id_embedding_dim=self.speaker_id_embedding_dim, in_spec_channels=self.spec_channels,
+            out_z_channels=self.z_channels, phoneme_embedding_dim=self.phoneme_embedding_dim)
+        self.decoder = Decoder(speaker_id_embedding_dim=self.speaker_id_embedding_dim, in_z_channel=self.z_channels)
+        self.flow = Flow(speaker_id_embedding_dim=self.speaker_id_embedding_dim, in_z_channels=self.z_channels,
+                         phoneme_embedding_dim=self.phoneme_embedding_dim)
+        self.stochastic_duration_predictor = StochasticDurationPredictor(
+            speaker_id_embedding_dim=self.speaker_id_embedding_dim, phoneme_embedding_dim=self.phoneme_embedding_dim,
+            filter_channels=192, kernel_size=3, p_dropout=0.5, n_flows=4)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("training forward (vits_generator.py:127-166) is out of scope of the inference build")
+
+    @torch.no_grad()
+    def frame_prior(self, text_padded, text_lengths, speaker_id, length_scale=1, noise_scale_w=0.8, noise_w=None):
+        """Lines 169-182 of ``text_to_speech``: token-level prior, sampled durations, hard
+        monotonic path, frame-level (m_p, logs_p).  Returns (m_p, logs_p, spec_mask, g)."""
+        text_encoded, m_p, logs_p, text_mask = self.text_encoder(text_padded, text_lengths)
+        g = self.embed_speaker(speaker_id)
+        logw = self.stochastic_duration_predictor(text_encoded, text_mask, speaker_id_embedded=g, reverse=True,
+                                                  noise_scale=noise_scale_w, noise=noise_w)
+        w_ceil = torch.ceil(torch.exp(logw) * text_mask * length_scale)
+        y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        spec_mask = torch.unsqueeze(sequence_mask(y_lengths, None), 1).to(text_mask.dtype)
+        node_mask = torch.unsqueeze(text_mask, 2) * torch.unsqueeze(spec_mask, -1)
+        path = generate_path(w_ceil, node_mask).squeeze(1)
+        m_p = torch.matmul(path, m_p.transpose(1, 2)).transpose(1, 2)
+        logs_p = torch.matmul(path, logs_p.transpose(1, 2)).transpose(1, 2)
+        return m_p, logs_p, spec_mask, g
+
+    @torch.no_grad()
+    def text_to_speech(self, text_padded, text_lengths, speaker_id, noise_scale=.667, length_scale=1,
+                       noise_scale_w=0.8, max_len=None, noise_w=None, noise_z=None):
+        """Same positional arguments and defaults as the reference; ``noise_w`` / ``noise_z``
+        optionally pin the two ``randn`` draws (duration predictor, latent)."""
+        m_p, logs_p, spec_mask, g = self.frame_prior(text_padded, text_lengths, speaker_id,
+                                                     length_scale=length_scale, noise_scale_w=noise_scale_w,
+                                                     noise_w=noise_w)
+        return self.synthesize_from_prior(m_p, logs_p, spec_mask, g, noise=noise_z, noise_scale=noise_scale,
+                                          max_len=max_len)

@@ -192,6 +192,55 @@ def hot_path_state_dict(seed: int = 999, n_speakers: int = 100, live_post: bool 
     return sd
 
 
+def front_half_state_dict(template, seed: int = 999):
+    """Deterministic values for every key of ``template`` (a state_dict of the text encoder /
+    duration predictor, or of a whole generator) that the hot-path generators above do not
+    cover.  Scales are chosen by parameter role so that attention, splines and durations
+    are all exercised (the reference zero-initialises the spline projections)."""
+    hot = ("decoder.", "flow.", "posterior_encoder.", "speaker_embedding.")
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, v in template.items():
+        if k.startswith(hot):
+            continue
+        shape = tuple(v.shape)
+        leaf = k.split(".")[-1]
+        parent = k.split(".")[-2] if "." in k else ""
+        is_norm = parent.isdigit() and "norm" in k.split(".")[-3]
+        if is_norm and leaf == "weight":
+            t = 1.0 + 0.1 * normal(seed, k, shape)
+        elif is_norm and leaf == "bias":
+            t = 0.05 * normal(seed, k, shape)
+        elif leaf in ("m", "logs"):
+            t = 0.1 * normal(seed, k, shape)
+        elif leaf.startswith("emb_rel") or k.endswith("emb.weight"):
+            t = normal(seed, k, shape) * shape[-1] ** -0.5
+        elif leaf == "bias":
+            t = 0.05 * normal(seed, k, shape)
+        elif leaf == "weight" and len(shape) == 3:
+            fan_in = shape[1] * shape[2]
+            gain = 3.0 if (parent == "proj" and "flows" in k) else (0.3 if k.endswith("text_encoder.projection.weight") else 1.0)
+            t = gain * normal(seed, k, shape) / np.sqrt(fan_in)
+        else:
+            raise KeyError(f"no generation rule for {k} {shape}")
+        out[k] = torch.from_numpy(np.asarray(t, dtype=np.float32))
+    return out
+
+
+def full_state_dict(template, seed: int = 999):
+    """Complete generator state_dict (858 keys for n_phoneme=40, n_speakers=100) in the
+    template's key order."""
+    hot = hot_path_state_dict(seed, n_speakers=template["speaker_embedding.weight"].shape[0])
+    front = front_half_state_dict(template, seed)
+    return OrderedDict((k, hot[k] if k in hot else front[k]) for k in template.keys())
+
+
+# phoneme ids of "k o r e w a t e s U t o o N s e e d e s U" interleaved with blanks (id 0), the
+# sentence of the reference's text-to-speech script (vits_text_to_speech.py:77-97); the symbol
+# table is not needed for random-init weights, any fixed ids below n_phoneme=40 do.
+TTS_SENTENCE_IDS = [0, 19, 0, 25, 0, 28, 0, 12, 0, 36, 0, 7, 0, 31, 0, 12, 0, 29, 0, 5, 0, 31, 0, 25, 0, 25, 0, 3,
+                    0, 29, 0, 12, 0, 12, 0, 11, 0, 12, 0, 29, 0, 5, 0]
+
+
 def strip_prefix(sd, prefix: str):
     """Sub-dict for one sub-module, keys relative to it (for ``load_state_dict``)."""
     p = prefix + "."
