@@ -40,7 +40,7 @@ static int64_t gemm_rows(const vk_conv_args* a)
     return a->c_out;
 }
 
-static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds)
+static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, int* vec)
 {
     if (!a) return vk_fail(VK_E_ARG, "vk_conv1d: null argument block");
     if (!a->x || !a->w || !a->out) return vk_fail(VK_E_ARG, "vk_conv1d: null x / w / out pointer");
@@ -80,10 +80,41 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds)
         break;
     default: break;
     }
+    if (a->act_in && !(a->in_slope >= 0.0f && a->in_slope <= 1.0f))
+        return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: leaky-ReLU slope must lie in [0, 1]");
+    // Buffer addressing: offsets within one batch item's view are 32-bit byte offsets.
+    auto span = [&](int64_t rows, int64_t cstride, int64_t len) -> int64_t {
+        return ((rows - 1) * (cstride < 0 ? -cstride : cstride) + len) * 4;
+    };
+    const int64_t out_len = ups ? (int64_t)a->length * a->up_stride : a->length;
+    const int64_t out_rows = (a->epilogue == VK_EPI_GATE || a->epilogue == VK_EPI_SAMPLE) ? a->hidden
+                           : (a->epilogue == VK_EPI_WN_MID ? a->hidden : a->c_out);
+    const int64_t xb = span(a->c_in, a->x_cstride, a->length);
+    const int64_t ob = span(out_rows, a->out_cstride, out_len);
+    const int64_t rb = a->res ? span(out_rows, a->res_cstride, a->length) : 0;
+    const int64_t o2 = a->out2 ? span(a->epilogue == VK_EPI_WN_MID ? a->c_out - a->hidden : out_rows, a->out2_cstride, a->length) : 0;
+    if (a->x_cstride < 0 || a->out_cstride < 0 || a->res_cstride < 0 || a->out2_cstride < 0)
+        return vk_fail(VK_E_ARG, "vk_conv1d: negative channel stride");
+    if (xb > 0x7fffffffLL || ob > 0x7fffffffLL || rb > 0x7fffffffLL || o2 > 0x7fffffffLL)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: one batch item's view spans more than 2 GiB");
     memset(d, 0, sizeof(*d));
     d->a = *a;
+    d->x_bytes = (unsigned)xb; d->out_bytes = (unsigned)ob; d->res_bytes = (unsigned)rb; d->out2_bytes = (unsigned)o2;
     d->nchunk = (a->c_in + G.ck - 1) / G.ck;
-    d->xw = TN + halo;
+    // 16-byte staging when every row of x starts 16-byte aligned and the length is a multiple of 4
+    static const int no_vec = getenv("VK_NO_VEC") != nullptr;
+    *vec = !no_vec && a->act_in &&
+           ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) && (a->length % 4 == 0) &&
+           (a->epilogue == VK_EPI_STORE || a->epilogue == VK_EPI_RESID || a->epilogue == VK_EPI_RESID_ACC ||
+            a->epilogue == VK_EPI_RESID_AVG || a->epilogue == VK_EPI_UPSAMPLE) && a->tile != VK_TILE_PAIR;
+    if (*vec) {
+        const int padv = (a->pad + 3) & ~3;
+        d->col0 = padv - a->pad;
+        d->xw = (TN + halo + d->col0 + 3) & ~3;
+    } else {
+        d->col0 = 0;
+        d->xw = TN + halo;
+    }
     d->lds_stride = d->xw;
     d->groups_per_mt = d->nchunk * a->taps * (G.ck / 8);
     static const int dbg = getenv("VK_DEBUG_SKIP") ? atoi(getenv("VK_DEBUG_SKIP")) : 0;
@@ -101,24 +132,24 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds)
 
 extern "C" int64_t vk_conv1d_lds_bytes(const vk_conv_args* a)
 {
-    ConvDev d; dim3 grid; size_t lds = 0;
-    int rc = derive(a, &d, &grid, &lds);
+    ConvDev d; dim3 grid; size_t lds = 0; int vec = 0;
+    int rc = derive(a, &d, &grid, &lds, &vec);
     return rc == VK_OK ? (int64_t)lds : (int64_t)rc;
 }
 
 extern "C" int vk_conv1d(const vk_conv_args* a, void* stream)
 {
-    ConvDev d; dim3 grid; size_t lds = 0;
-    int rc = derive(a, &d, &grid, &lds);
+    ConvDev d; dim3 grid; size_t lds = 0; int vec = 0;
+    int rc = derive(a, &d, &grid, &lds, &vec);
     if (rc != VK_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int act = a->act_in ? 1 : 0;
     int e = -1;
     switch (a->tile) {
-    case VK_TILE_M128: e = vk_launch_tile0(a->epilogue, act, d, grid, lds, s); break;
-    case VK_TILE_M64:  e = vk_launch_tile1(a->epilogue, act, d, grid, lds, s); break;
-    case VK_TILE_M32:  e = vk_launch_tile2(a->epilogue, act, d, grid, lds, s); break;
-    case VK_TILE_PAIR: e = vk_launch_tile3(a->epilogue, act, d, grid, lds, s); break;
+    case VK_TILE_M128: e = vk_launch_tile0(a->epilogue, act, vec, d, grid, lds, s); break;
+    case VK_TILE_M64:  e = vk_launch_tile1(a->epilogue, act, vec, d, grid, lds, s); break;
+    case VK_TILE_M32:  e = vk_launch_tile2(a->epilogue, act, vec, d, grid, lds, s); break;
+    case VK_TILE_PAIR: e = vk_launch_tile3(a->epilogue, act, vec, d, grid, lds, s); break;
     }
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: this (tile, epilogue, act_in) combination is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));

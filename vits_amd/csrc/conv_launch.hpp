@@ -14,14 +14,14 @@ static constexpr TileGeom kTiles[VK_TILE_COUNT] = {
 };
 
 // Returns hipSuccess / a HIP error, or -1 when (epilogue, act_in) is not built for the tile.
-int vk_launch_tile0(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
-int vk_launch_tile1(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
-int vk_launch_tile2(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
-int vk_launch_tile3(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile0(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile1(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile2(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile3(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
 
-#define VK_CONV_CASE(EPI, ACT)                                                                   \
-    if (epi == (EPI) && act == (ACT)) {                                                          \
-        auto k = conv_mfma_kernel<G.a_rep, G.b_rep, G.wm, G.wn, G.ck, (EPI), (ACT) != 0>;        \
+#define VK_CONV_CASE(EPI, ACT, VEC)                                                              \
+    if (epi == (EPI) && act == (ACT) && vec == (VEC)) {                                          \
+        auto k = conv_mfma_kernel<G.a_rep, G.b_rep, G.wm, G.wn, G.ck, (EPI), (ACT) != 0, (VEC) != 0>; \
         if (lds > 65536) {                                                                       \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -31,15 +31,21 @@ int vk_launch_tile3(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, h
         return (int)hipGetLastError();                                                           \
     }
 
-#define VK_PLAIN_TILE_BODY()                  \
-    VK_CONV_CASE(VK_EPI_STORE, 0)             \
-    VK_CONV_CASE(VK_EPI_STORE, 1)             \
-    VK_CONV_CASE(VK_EPI_RESID, 1)             \
-    VK_CONV_CASE(VK_EPI_RESID_ACC, 1)         \
-    VK_CONV_CASE(VK_EPI_RESID_AVG, 1)         \
-    VK_CONV_CASE(VK_EPI_UPSAMPLE, 1)          \
-    VK_CONV_CASE(VK_EPI_WN_MID, 0)            \
-    VK_CONV_CASE(VK_EPI_WN_LAST, 0)           \
-    VK_CONV_CASE(VK_EPI_COUPLE_REV, 0)        \
-    VK_CONV_CASE(VK_EPI_COUPLE_FWD, 0)        \
+// (epilogue, act_in, vector staging) combinations that are built for the plain tiles
+#define VK_PLAIN_TILE_BODY()                     \
+    VK_CONV_CASE(VK_EPI_STORE, 0, 0)             \
+    VK_CONV_CASE(VK_EPI_STORE, 1, 0)             \
+    VK_CONV_CASE(VK_EPI_STORE, 1, 1)             \
+    VK_CONV_CASE(VK_EPI_RESID, 1, 0)             \
+    VK_CONV_CASE(VK_EPI_RESID, 1, 1)             \
+    VK_CONV_CASE(VK_EPI_RESID_ACC, 1, 0)         \
+    VK_CONV_CASE(VK_EPI_RESID_ACC, 1, 1)         \
+    VK_CONV_CASE(VK_EPI_RESID_AVG, 1, 0)         \
+    VK_CONV_CASE(VK_EPI_RESID_AVG, 1, 1)         \
+    VK_CONV_CASE(VK_EPI_UPSAMPLE, 1, 0)          \
+    VK_CONV_CASE(VK_EPI_UPSAMPLE, 1, 1)          \
+    VK_CONV_CASE(VK_EPI_WN_MID, 0, 0)            \
+    VK_CONV_CASE(VK_EPI_WN_LAST, 0, 0)           \
+    VK_CONV_CASE(VK_EPI_COUPLE_REV, 0, 0)        \
+    VK_CONV_CASE(VK_EPI_COUPLE_FWD, 0, 0)        \
     return -1;

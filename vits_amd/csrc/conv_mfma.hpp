@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/vits_amd.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,12 +31,154 @@ struct ConvDev {
     int xw;             // staged columns per row: time tile + halo
     int lds_stride;     // floats between staged rows
     int groups_per_mt;  // 64-lane x float4 groups per 32-row tile: nchunk * taps * CK / 8
+    int col0;           // staged column of time t0 - pad (vector staging starts at a multiple of 4 columns)
+    unsigned x_bytes, out_bytes, res_bytes, out2_bytes;   // byte spans of one batch item's views (buffer bounds)
     unsigned long long* stamps;   // diagnostic: 8 x u64 per workgroup (times, placement) or null
     int dbg;            // timing experiments only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop,
                         // 4 = stage only the first chunk, 8 = barrier only on the first chunk
 };
 
 __device__ __forceinline__ float vk_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer addressing: a wave-uniform descriptor per tensor view, the row offset in a scalar
+// register and the per-lane column offset in one VGPR, so loads and stores need no per-access
+// vector address arithmetic (every vector instruction issued in a load/store phase competes
+// with the other waves' matrix instructions for the SIMD).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vk_rsrc(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float vk_bld(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void vk_bst(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
+}
+// leaky-ReLU with 0 <= slope <= 1 is max(v, slope * v); one v_max_f32 without the compiler's
+// canonicalising pre-max (NaN in gives NaN out either way).
+__device__ __forceinline__ float vk_lrelu(float v, float slope)
+{
+    float r;
+    const float sv = v * slope;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+    return r;
+}
+
+// Staging of one K-chunk, 4 bytes per lane per load: any length and alignment.
+template <int RPW, int NJ, int NW, int CK, bool ACT>
+struct ScalarStager {
+    int toff[NJ];               // clamped byte offset of column j*64 + lane within a row
+    unsigned inrange;           // bit j: that column lies inside [0, L)
+    bool last_col_ok;
+    float st[RPW][NJ];
+    __amdgpu_buffer_rsrc_t rx;
+
+    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane)
+    {
+        const int L = d.a.length;
+        rx = vk_rsrc(xb, d.x_bytes);
+        inrange = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int t = t0 - d.a.pad + lane + 64 * j;
+            toff[j] = 4 * (t < 0 ? 0 : (t >= L ? L - 1 : t));
+            if (t >= 0 && t < L) inrange |= 1u << j;
+        }
+        last_col_ok = (lane + 64 * (NJ - 1)) < d.xw;          // only the last piece can overhang
+    }
+    __device__ __forceinline__ void issue(const ConvDev& d, int chunk, int w)
+    {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int c = chunk * CK + w + r * NW;                                  // wave-uniform
+            const int soff = (int)((c < d.a.c_in ? c : 0) * d.a.x_cstride * 4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) st[r][j] = vk_bld(rx, toff[j], soff);      // the select happens at store time
+        }
+    }
+    __device__ __forceinline__ void store(const ConvDev& d, int chunk, float* buf, int w, int lane)
+    {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int cl = w + r * NW;
+            const bool cok = (chunk * CK + cl) < d.a.c_in;
+            float* dst = buf + cl * d.lds_stride + lane;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float v = (cok && ((inrange >> j) & 1u)) ? st[r][j] : 0.0f;
+                if (ACT) v = vk_lrelu(v, d.a.in_slope);
+                if (j < NJ - 1 || last_col_ok) dst[64 * j] = v;
+            }
+        }
+    }
+};
+
+// Staging of one K-chunk, 16 bytes per lane per load: rows 16-byte aligned and L % 4 == 0.  The
+// staged tile starts at a column that is a multiple of 4, so each float4 lies wholly inside or
+// wholly outside [0, L); interior tiles skip the validity selects altogether.
+template <int RPW, int NJ4, int NW, int CK, bool ACT>
+struct VectorStager {
+    int voff[NJ4];              // clamped byte offset of float4 number j*64 + lane within a row
+    unsigned inrange, wanted;   // bit j: float4 inside [0, L) / inside the staged width
+    bool edge;                  // wave-uniform: some float4 of this tile is out of range
+    float4 st[RPW][NJ4];
+    __amdgpu_buffer_rsrc_t rx;
+
+    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane)
+    {
+        const int L = d.a.length;
+        const int ts = t0 - d.a.pad - d.col0;                   // multiple of 4
+        rx = vk_rsrc(xb, d.x_bytes);
+        inrange = 0; wanted = 0;
+#pragma unroll
+        for (int j = 0; j < NJ4; ++j) {
+            const int c4 = lane + 64 * j;
+            const int t = ts + 4 * c4;
+            voff[j] = 4 * (t < 0 ? 0 : (t > L - 4 ? L - 4 : t));
+            if (t >= 0 && t + 4 <= L) inrange |= 1u << j;
+            if (4 * c4 < d.xw) wanted |= 1u << j;
+        }
+        edge = (ts < 0) || (ts + d.xw > L);
+    }
+    __device__ __forceinline__ void issue(const ConvDev& d, int chunk, int w)
+    {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int c = chunk * CK + w + r * NW;
+            const int soff = (int)((c < d.a.c_in ? c : 0) * d.a.x_cstride * 4);
+#pragma unroll
+            for (int j = 0; j < NJ4; ++j)
+                st[r][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[j], soff, 0));
+        }
+    }
+    __device__ __forceinline__ void store(const ConvDev& d, int chunk, float* buf, int w, int lane)
+    {
+        const bool chan_edge = (chunk + 1) * CK > d.a.c_in;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int cl = w + r * NW;
+            float4* dst = reinterpret_cast<float4*>(buf + cl * d.lds_stride) + lane;
+#pragma unroll
+            for (int j = 0; j < NJ4; ++j) {
+                float4 v = st[r][j];
+                if (edge || chan_edge) {
+                    const bool ok = ((chunk * CK + cl) < d.a.c_in) && ((inrange >> j) & 1u);
+                    v.x = ok ? v.x : 0.0f; v.y = ok ? v.y : 0.0f; v.z = ok ? v.z : 0.0f; v.w = ok ? v.w : 0.0f;
+                }
+                if (ACT) {
+                    v.x = vk_lrelu(v.x, d.a.in_slope); v.y = vk_lrelu(v.y, d.a.in_slope);
+                    v.z = vk_lrelu(v.z, d.a.in_slope); v.w = vk_lrelu(v.w, d.a.in_slope);
+                }
+                if ((wanted >> j) & 1u) dst[64 * j] = v;
+            }
+        }
+    }
+};
 
 // Diagnostic time stamps (100 MHz constant clock); written only when a stamp buffer is set.
 __device__ __forceinline__ void vk_stamp(const ConvDev& d, int slot)
@@ -48,7 +191,7 @@ __device__ __forceinline__ void vk_stamp(const ConvDev& d, int slot)
     }
 }
 
-template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT>
+template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT, bool VEC>
 __global__ void __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN)) > 0 ? (512 / (64 * WM * WN)) : 1)
 conv_mfma_kernel(const ConvDev d)
 {
@@ -56,6 +199,7 @@ conv_mfma_kernel(const ConvDev d)
     constexpr int TNW = 32 * B_REP;          // time steps per wave
     constexpr int TN  = TNW * WN;            // time steps per workgroup
     constexpr int NJ  = TN / 64 + 1;         // 64-column pieces per staged row (halo <= 64)
+    constexpr int NJ4 = (TN + 70 + 255) / 256;   // 64-lane x float4 pieces per staged row (vector staging)
     constexpr int RPW = CK / NW;             // staged rows per wave per chunk
     constexpr int GPC = CK / 8;              // weight groups per (chunk, tap)
     static_assert(CK % NW == 0 && CK % 8 == 0, "chunk must split over waves and k-groups");
@@ -76,48 +220,20 @@ conv_mfma_kernel(const ConvDev d)
     const int t0   = blockIdx.x * TN;
     const int mt0  = (blockIdx.y * WM + wm) * A_REP;   // first packed 32-row tile of this wave
     const int L    = p.length;
-    const int ts   = t0 - p.pad;                       // time of staged column 0
     const int stride = d.lds_stride;
 
     const float* xb = p.x + (int64_t)b * p.x_bstride;
     vk_stamp(d, 0);
 
     // ---- staging: global -> registers (issued early) -> LDS (written after the barrier) ----
-    // Column j*64 + lane of the staged tile is time ts + j*64 + lane for every row and chunk,
-    // so the clamped load offsets and the in-range bits are computed once.
-    int toff[NJ];
-    unsigned inrange = 0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int t = ts + lane + 64 * j;
-        toff[j] = t < 0 ? 0 : (t >= L ? L - 1 : t);
-        if (t >= 0 && t < L) inrange |= 1u << j;
-    }
-    const bool last_col_ok = (lane + 64 * (NJ - 1)) < d.xw;      // only the last piece can overhang
-    float stage[RPW][NJ];
-    auto issue_loads = [&](int chunk) {
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int c = chunk * CK + w + r * NW;                        // wave-uniform
-            const float* row = xb + (int64_t)(c < p.c_in ? c : 0) * p.x_cstride;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) stage[r][j] = row[toff[j]];      // the select happens at store time
-        }
-    };
-    auto store_chunk = [&](int chunk, float* buf) {
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int cl = w + r * NW;
-            const bool cok = (chunk * CK + cl) < p.c_in;
-            float* dst = buf + cl * stride + lane;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float v = (cok && ((inrange >> j) & 1u)) ? stage[r][j] : 0.0f;
-                if (ACT) v = v > 0.0f ? v : v * p.in_slope;
-                if (j < NJ - 1 || last_col_ok) dst[64 * j] = v;
-            }
-        }
-    };
+    // The column layout of the staged tile is the same for every row and chunk of the tile, so
+    // load offsets and in-range bits are computed once (see the stager structs above).
+    using Stager = typename std::conditional<VEC, VectorStager<RPW, NJ4, NW, CK, ACT>,
+                                                  ScalarStager<RPW, NJ, NW, CK, ACT>>::type;
+    Stager stg;
+    stg.init(d, xb, t0, lane);
+    auto issue_loads = [&](int chunk) { stg.issue(d, chunk, w); };
+    auto store_chunk = [&](int chunk, float* buf) { stg.store(d, chunk, buf, w, lane); };
 
     // ---- weight stream: one float4 per lane per 4 k-steps per row tile ----
     const float4* aptr[A_REP];
@@ -139,7 +255,7 @@ conv_mfma_kernel(const ConvDev d)
         const int phase = (mt0 * 32) / p.c_out;
         shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
     }
-    const int bcol = half * stride + wn * TNW + l31 + shift;
+    const int bcol = half * stride + wn * TNW + l31 + shift + d.col0;
     
     // Weight fragments are fetched one whole tap (GPC groups) ahead: the loads for tap+1 are
     // issued when tap starts and first touched when it ends, so a full tap of MFMAs covers
@@ -280,6 +396,7 @@ conv_mfma_kernel(const ConvDev d)
             }
         } else if constexpr (EPI == VK_EPI_UPSAMPLE) {
             const int S = p.up_stride;
+            const __amdgpu_buffer_rsrc_t r_out = vk_rsrc(p.out + ob, d.out_bytes);
 #pragma unroll
             for (int m = 0; m < A_REP; ++m) {
                 const int prow0 = (mt0 + m) * 32;
@@ -292,17 +409,24 @@ conv_mfma_kernel(const ConvDev d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) bv[r] = biasb[co0 + (r & 3) + 8 * (r >> 2) + 4 * half];
                 }
+                const int vo = 4 * (4 * half * (int)p.out_cstride + tw * S + phase);
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
-                    const int loff = 4 * half * (int)p.out_cstride + (tw + 32 * n) * S + phase;
+                    const int von = vo + 128 * n * S;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float* op = p.out + ob + (int64_t)(co0 + (r & 3) + 8 * (r >> 2)) * p.out_cstride;
-                        op[loff] = acc[m][n][r] + bv[r];
-                    }
+                    for (int r = 0; r < 16; ++r)
+                        vk_bst(acc[m][n][r] + bv[r], r_out, von, (co0 + (r & 3) + 8 * (r >> 2)) * (int)p.out_cstride * 4);
                 }
             }
         } else {
+            // buffer descriptors of this batch item's views; row offsets are scalar, the lane's
+            // column offset is one VGPR per view, the column tile n is an immediate
+            const __amdgpu_buffer_rsrc_t r_out  = vk_rsrc(p.out + ob, d.out_bytes);
+            const __amdgpu_buffer_rsrc_t r_res  = vk_rsrc(p.res ? p.res + rb : p.out + ob, p.res ? d.res_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t r_out2 = vk_rsrc(p.out2 ? p.out2 + o2b : p.out + ob, p.out2 ? d.out2_bytes : 0u);
+            const int vo  = 4 * (4 * half * (int)p.out_cstride + tw);
+            const int vr  = 4 * (4 * half * (int)p.res_cstride + tw);
+            const int vo2 = 4 * (4 * half * (int)p.out2_cstride + tw);
 #pragma unroll
             for (int m = 0; m < A_REP; ++m) {
                 const int R0 = (mt0 + m) * 32;
@@ -316,31 +440,27 @@ conv_mfma_kernel(const ConvDev d)
                 const bool skip_half = (EPI == VK_EPI_WN_MID) && (R0 >= p.hidden);     // wave-uniform
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
-                    const int t = tw + 32 * n;
-                    const float mkv = maskb ? maskb[t] : 1.0f;
-                    const int olo  = 4 * half * (int)p.out_cstride + t;
-                    const int rlo  = 4 * half * (int)p.res_cstride + t;
-                    const int o2lo = 4 * half * (int)p.out2_cstride + t;
-                    float rv[16], sv[16];
+                    const float mkv = maskb ? maskb[tw + 32 * n] : 1.0f;
                     constexpr bool NEED_RES = (EPI == VK_EPI_RESID || EPI == VK_EPI_RESID_ACC || EPI == VK_EPI_RESID_AVG ||
                                                EPI == VK_EPI_WN_MID || EPI == VK_EPI_COUPLE_REV || EPI == VK_EPI_COUPLE_FWD);
                     constexpr bool NEED_ACC = (EPI == VK_EPI_RESID_ACC || EPI == VK_EPI_RESID_AVG ||
                                                EPI == VK_EPI_WN_MID || EPI == VK_EPI_WN_LAST);
+                    float rv[16], sv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rr = R0 + (r & 3) + 8 * (r >> 2);
                         rv[r] = 0.0f; sv[r] = 0.0f;
                         if constexpr (NEED_RES) {
-                            if (!skip_half) rv[r] = (p.res + rb + (int64_t)rr * p.res_cstride)[rlo];
+                            if (!skip_half) rv[r] = vk_bld(r_res, vr + 128 * n, rr * (int)p.res_cstride * 4);
                         }
                         if constexpr (NEED_ACC) {
                             if constexpr (EPI == VK_EPI_WN_MID) {
                                 if (skip_half && !p.first)
-                                    sv[r] = (p.out2 + o2b + (int64_t)(rr - p.hidden) * p.out2_cstride)[o2lo];
+                                    sv[r] = vk_bld(r_out2, vo2 + 128 * n, (rr - p.hidden) * (int)p.out2_cstride * 4);
                             } else if constexpr (EPI == VK_EPI_WN_LAST) {
-                                if (!p.first) sv[r] = (p.out2 + o2b + (int64_t)rr * p.out2_cstride)[o2lo];
+                                if (!p.first) sv[r] = vk_bld(r_out2, vo2 + 128 * n, rr * (int)p.out2_cstride * 4);
                             } else {
-                                sv[r] = (p.out2 + o2b + (int64_t)rr * p.out2_cstride)[o2lo];
+                                sv[r] = vk_bld(r_out2, vo2 + 128 * n, rr * (int)p.out2_cstride * 4);
                             }
                         }
                     }
@@ -348,24 +468,25 @@ conv_mfma_kernel(const ConvDev d)
                     for (int r = 0; r < 16; ++r) {
                         const int rr = R0 + (r & 3) + 8 * (r >> 2);
                         const float v = acc[m][n][r] + bv[r];
-                        float* op = p.out + ob + (int64_t)rr * p.out_cstride;
+                        const int so = rr * (int)p.out_cstride * 4;
+                        const int voo = vo + 128 * n;
                         if constexpr (EPI == VK_EPI_STORE) {
-                            op[olo] = v * mkv;
+                            vk_bst(v * mkv, r_out, voo, so);
                         } else if constexpr (EPI == VK_EPI_RESID) {
-                            op[olo] = v + rv[r];
+                            vk_bst(v + rv[r], r_out, voo, so);
                         } else if constexpr (EPI == VK_EPI_RESID_ACC) {
-                            op[olo] = sv[r] + (v + rv[r]);
+                            vk_bst(sv[r] + (v + rv[r]), r_out, voo, so);
                         } else if constexpr (EPI == VK_EPI_RESID_AVG) {
-                            op[olo] = (sv[r] + (v + rv[r])) / p.navg;
+                            vk_bst((sv[r] + (v + rv[r])) / p.navg, r_out, voo, so);
                         } else if constexpr (EPI == VK_EPI_WN_MID) {
-                            if (!skip_half) op[olo] = (rv[r] + v) * mkv;
-                            else (p.out2 + o2b + (int64_t)(rr - p.hidden) * p.out2_cstride)[o2lo] = sv[r] + v;
+                            if (!skip_half) vk_bst((rv[r] + v) * mkv, r_out, voo, so);
+                            else vk_bst(sv[r] + v, r_out2, vo2 + 128 * n, (rr - p.hidden) * (int)p.out2_cstride * 4);
                         } else if constexpr (EPI == VK_EPI_WN_LAST) {
-                            op[olo] = (sv[r] + v) * mkv;
+                            vk_bst((sv[r] + v) * mkv, r_out, voo, so);
                         } else if constexpr (EPI == VK_EPI_COUPLE_REV) {
-                            op[olo] = (rv[r] - v * mkv) * mkv;
+                            vk_bst((rv[r] - v * mkv) * mkv, r_out, voo, so);
                         } else if constexpr (EPI == VK_EPI_COUPLE_FWD) {
-                            op[olo] = v * mkv + rv[r] * mkv;
+                            vk_bst(v * mkv + rv[r] * mkv, r_out, voo, so);
                         }
                     }
                 }

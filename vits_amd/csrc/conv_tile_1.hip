@@ -1,5 +1,5 @@
 #include "conv_launch.hpp"
-int vk_launch_tile1(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s)
+int vk_launch_tile1(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s)
 {
     constexpr TileGeom G = kTiles[1];
     VK_PLAIN_TILE_BODY()
