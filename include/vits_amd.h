@@ -51,7 +51,7 @@ typedef struct {
 #define VK_TILE_M128  0   /* 128 rows x 128 cols, 4 waves split rows        (C_out >= 128) */
 #define VK_TILE_M64   1   /*  64 rows x 256 cols, 2x2 waves                 (C_out 64/192) */
 #define VK_TILE_M32   2   /*  32 rows x 512 cols, 4 waves split time        (C_out 32/96)  */
-#define VK_TILE_PAIR  3   /* 128 rows x 256 cols, row tiles in (a,b) pairs  (gated / split outputs) */
+#define VK_TILE_PAIR  3   /* 128 rows x 128 cols, row tiles in (a,b) pairs  (gated / split outputs) */
 #define VK_TILE_COUNT 4
 
 /* Epilogues (vk_conv_args.epilogue); v = accumulator + bias[row].

@@ -115,7 +115,7 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
         d->col0 = 0;
         d->xw = TN + halo;
     }
-    d->lds_stride = d->xw;
+    d->lds_stride = TN + 68;              // compile-time constant of the kernel: tile + halo (<= 64) + alignment slack
     d->groups_per_mt = d->nchunk * a->taps * (G.ck / 8);
     static const int dbg = getenv("VK_DEBUG_SKIP") ? atoi(getenv("VK_DEBUG_SKIP")) : 0;
     d->dbg = dbg;

@@ -220,7 +220,7 @@ conv_mfma_kernel(const ConvDev d)
     const int t0   = blockIdx.x * TN;
     const int mt0  = (blockIdx.y * WM + wm) * A_REP;   // first packed 32-row tile of this wave
     const int L    = p.length;
-    const int stride = d.lds_stride;
+    constexpr int STRIDE = TN + 68;          // floats between staged rows (>= tile + 64-column halo + alignment slack)
 
     const float* xb = p.x + (int64_t)b * p.x_bstride;
     vk_stamp(d, 0);
@@ -241,13 +241,33 @@ conv_mfma_kernel(const ConvDev d)
     for (int m = 0; m < A_REP; ++m)
         aptr[m] = reinterpret_cast<const float4*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
 
+    // Accumulators start at the bias of their row (so no epilogue adds it): register r of this
+    // lane is row (r & 3) + 8 * (r >> 2) + 4 * half of the 32-row tile.
     f32x16 acc[A_REP][B_REP];
+    {
+        const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
+        const int rows_total_b = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
 #pragma unroll
-    for (int m = 0; m < A_REP; ++m)
+        for (int m = 0; m < A_REP; ++m) {
+            float bv[16];
 #pragma unroll
-        for (int n = 0; n < B_REP; ++n)
+            for (int r = 0; r < 16; ++r) {
+                const int prow = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // packed row
+                int brow = prow;                                                        // bias index
+                if (PAIR) brow = ((m & 1) ? p.hidden : 0) + 32 * ((mt0 + m) >> 1) + (prow & 31);
+                if (EPI == VK_EPI_UPSAMPLE) brow = prow % p.c_out;
+                bv[r] = 0.0f;
+                if (biasb != nullptr) {                      // wave-uniform
+                    const float raw = biasb[prow < rows_total_b ? brow : 0];
+                    bv[r] = prow < rows_total_b ? raw : 0.0f;
+                }
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+            for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = bv[r];
+        }
+    }
 
     // transposed conv: row tiles of the upper phases read the staged tile one column later
     int shift = 0;
@@ -255,7 +275,7 @@ conv_mfma_kernel(const ConvDev d)
         const int phase = (mt0 * 32) / p.c_out;
         shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
     }
-    const int bcol = half * stride + wn * TNW + l31 + shift + d.col0;
+    const int bcol = half * STRIDE + wn * TNW + l31 + shift + d.col0;
     
     // Weight fragments are fetched one whole tap (GPC groups) ahead: the loads for tap+1 are
     // issued when tap starts and first touched when it ends, so a full tap of MFMAs covers
@@ -269,7 +289,7 @@ conv_mfma_kernel(const ConvDev d)
     issue_loads(0);
     unsigned long long boundary_ticks = 0;      // diagnostic: time spent handing over chunks 1..n-1
     for (int chunk = 0; chunk < d.nchunk; ++chunk) {
-        float* buf = lds + (chunk & 1) * (CK * stride);
+        float* buf = lds + (chunk & 1) * (CK * STRIDE);
         unsigned long long tb0 = 0;
         if (d.stamps) tb0 = __builtin_amdgcn_s_memrealtime();
         if (!(d.dbg & 4) || chunk == 0) store_chunk(chunk, buf);
@@ -280,15 +300,15 @@ conv_mfma_kernel(const ConvDev d)
         if (d.dbg & 2) continue;
 
         // k-steps walk channel pairs within a tap, then taps; the B fragments of the next
-        // k-step are read from LDS before the current k-step's MFMAs are issued.
-        const float* bk = buf + bcol;
+        // k-step are read from LDS before the current k-step's MFMAs are issued.  Within a tap
+        // every read is the tap's base address plus a compile-time offset.
+        const float* bt = buf + bcol;
         float bf[B_REP];
 #pragma unroll
-        for (int n = 0; n < B_REP; ++n) bf[n] = bk[32 * n];
+        for (int n = 0; n < B_REP; ++n) bf[n] = bt[32 * n];
 #pragma unroll 1
         for (int tap = 0; tap < p.taps; ++tap) {
-            const float* next_tap = (tap + 1 < p.taps) ? buf + bcol + (tap + 1) * p.dilation
-                                                       : buf + bcol;      // chunk end: harmless re-read
+            const float* bt_next = (tap + 1 < p.taps) ? bt + p.dilation : buf + bcol;   // chunk end: harmless re-read
             float4 a_nxt[GPC][A_REP];
 #pragma unroll
             for (int g = 0; g < GPC; ++g)
@@ -302,10 +322,12 @@ conv_mfma_kernel(const ConvDev d)
                 for (int m = 0; m < A_REP; ++m) a_cur[m] = a[g][m];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float* nk = (g == GPC - 1 && e == 3) ? next_tap : bk + 2 * stride;
+                    constexpr int KSTEPS = 4 * GPC;
+                    const int ks = 4 * g + e;
                     float bn[B_REP];
 #pragma unroll
-                    for (int n = 0; n < B_REP; ++n) bn[n] = nk[32 * n];
+                    for (int n = 0; n < B_REP; ++n)
+                        bn[n] = (ks + 1 < KSTEPS) ? bt[2 * (ks + 1) * STRIDE + 32 * n] : bt_next[32 * n];
 #pragma unroll
                     for (int m = 0; m < A_REP; ++m) {
                         const float av = (e == 0) ? a_cur[m].x : (e == 1) ? a_cur[m].y
@@ -316,11 +338,11 @@ conv_mfma_kernel(const ConvDev d)
                     }
 #pragma unroll
                     for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
-                    bk = nk;
                     __builtin_amdgcn_sched_group_barrier(0x100, (B_REP + 1) / 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, A_REP * B_REP, 0);
                 }
             }
+            bt = bt_next;
 #pragma unroll
             for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * GPC;
 #pragma unroll
@@ -341,7 +363,6 @@ conv_mfma_kernel(const ConvDev d)
     const int64_t ob  = (int64_t)b * p.out_bstride;
     const int64_t rb  = (int64_t)b * p.res_bstride;
     const int64_t o2b = (int64_t)b * p.out2_bstride;
-    const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
     const int rows_total = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
     const bool interior = (t0 + wn * TNW + TNW <= L) && ((mt0 + A_REP) * 32 <= rows_total);
     if ((d.dbg & 1) && acc[0][0][0] != 12345.678f) return;
@@ -352,17 +373,6 @@ conv_mfma_kernel(const ConvDev d)
 #pragma unroll
             for (int m = 0; m < A_REP; m += 2) {
                 const int R0 = 16 * (mt0 + m);            // first output row of the pair (32 * q)
-                float ba[16], bb[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { ba[r] = 0.0f; bb[r] = 0.0f; }
-                if (biasb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = R0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        ba[r] = biasb[row];
-                        bb[r] = biasb[p.hidden + row];
-                    }
-                }
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
                     const int t = tw + 32 * n;
@@ -379,8 +389,8 @@ conv_mfma_kernel(const ConvDev d)
                     for (int r = 0; r < 16; ++r) {
                         const int rr = R0 + (r & 3) + 8 * (r >> 2);
                         const int loff = 4 * half * (int)p.out_cstride + t;
-                        const float va = acc[m][n][r] + ba[r];
-                        const float vb = acc[m + 1][n][r] + bb[r];
+                        const float va = acc[m][n][r];
+                        const float vb = acc[m + 1][n][r];
                         float* op = p.out + ob + (int64_t)rr * p.out_cstride;
                         if constexpr (EPI == VK_EPI_GATE) {
                             op[loff] = tanhf(va) * vk_sigmoid(vb);
@@ -402,20 +412,13 @@ conv_mfma_kernel(const ConvDev d)
                 const int prow0 = (mt0 + m) * 32;
                 const int phase = prow0 / p.c_out;
                 const int co0 = prow0 - phase * p.c_out;
-                float bv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
-                if (biasb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) bv[r] = biasb[co0 + (r & 3) + 8 * (r >> 2) + 4 * half];
-                }
                 const int vo = 4 * (4 * half * (int)p.out_cstride + tw * S + phase);
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
                     const int von = vo + 128 * n * S;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        vk_bst(acc[m][n][r] + bv[r], r_out, von, (co0 + (r & 3) + 8 * (r >> 2)) * (int)p.out_cstride * 4);
+                        vk_bst(acc[m][n][r], r_out, von, (co0 + (r & 3) + 8 * (r >> 2)) * (int)p.out_cstride * 4);
                 }
             }
         } else {
@@ -430,13 +433,6 @@ conv_mfma_kernel(const ConvDev d)
 #pragma unroll
             for (int m = 0; m < A_REP; ++m) {
                 const int R0 = (mt0 + m) * 32;
-                float bv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
-                if (biasb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) bv[r] = biasb[R0 + (r & 3) + 8 * (r >> 2) + 4 * half];
-                }
                 const bool skip_half = (EPI == VK_EPI_WN_MID) && (R0 >= p.hidden);     // wave-uniform
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
@@ -467,7 +463,7 @@ conv_mfma_kernel(const ConvDev d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rr = R0 + (r & 3) + 8 * (r >> 2);
-                        const float v = acc[m][n][r] + bv[r];
+                        const float v = acc[m][n][r];
                         const int so = rr * (int)p.out_cstride * 4;
                         const int voo = vo + 128 * n;
                         if constexpr (EPI == VK_EPI_STORE) {
@@ -513,14 +509,12 @@ conv_mfma_kernel(const ConvDev d)
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row >= p.hidden) continue;
-                const float ba = biasb ? biasb[row] : 0.0f;
-                const float bb = biasb ? biasb[p.hidden + row] : 0.0f;
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
                     const int t = tw + 32 * n;
                     if (t >= L) continue;
-                    const float va = acc[m][n][r] + ba;
-                    const float vb = acc[m + 1][n][r] + bb;
+                    const float va = acc[m][n][r];
+                    const float vb = acc[m + 1][n][r];
                     const int64_t o = ob + (int64_t)row * p.out_cstride + t;
                     if constexpr (EPI == VK_EPI_GATE) {
                         p.out[o] = tanhf(va) * vk_sigmoid(vb);
@@ -545,12 +539,11 @@ conv_mfma_kernel(const ConvDev d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float bv = biasb ? biasb[co] : 0.0f;
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
                     const int t = tw + 32 * n;
                     if (t >= L) continue;
-                    p.out[(int64_t)b * p.out_bstride + (int64_t)co * p.out_cstride + (int64_t)t * S + phase] = acc[m][n][r] + bv;
+                    p.out[(int64_t)b * p.out_bstride + (int64_t)co * p.out_cstride + (int64_t)t * S + phase] = acc[m][n][r];
                 }
             }
         }
@@ -561,12 +554,11 @@ conv_mfma_kernel(const ConvDev d)
             for (int r = 0; r < 16; ++r) {
                 const int row = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row >= p.c_out) continue;
-                const float bv = biasb ? biasb[row] : 0.0f;
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
                     const int t = tw + 32 * n;
                     if (t >= L) continue;
-                    const float v = acc[m][n][r] + bv;
+                    const float v = acc[m][n][r];
                     if constexpr (EPI == VK_EPI_STORE) {
                         p.out[ob + (int64_t)row * p.out_cstride + t] = v * mk[n];
                     } else if constexpr (EPI == VK_EPI_RESID) {
