@@ -85,7 +85,9 @@ struct ScalarStager {
         inrange = 0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int t = t0 - d.a.pad + lane + 64 * j;
+            int col = lane + 64 * j;
+            col = col < d.xw ? col : d.xw - 1;                // lanes past the staged width re-read its last column
+            const int t = t0 - d.a.pad + col;
             toff[j] = 4 * (t < 0 ? 0 : (t >= L ? L - 1 : t));
             if (t >= 0 && t < L) inrange |= 1u << j;
         }
@@ -138,10 +140,10 @@ struct VectorStager {
 #pragma unroll
         for (int j = 0; j < NJ4; ++j) {
             const int c4 = lane + 64 * j;
-            const int t = ts + 4 * c4;
+            if (4 * c4 < d.xw) wanted |= 1u << j;
+            const int t = ts + (4 * c4 < d.xw ? 4 * c4 : d.xw - 4);   // lanes past the staged width re-read its last float4
             voff[j] = 4 * (t < 0 ? 0 : (t > L - 4 ? L - 4 : t));
             if (t >= 0 && t + 4 <= L) inrange |= 1u << j;
-            if (4 * c4 < d.xw) wanted |= 1u << j;
         }
         edge = (ts < 0) || (ts + d.xw > L);
     }
