@@ -1,0 +1,168 @@
+"""Kernel-level GPU tests through the C ABI: the fused convolution against plain PyTorch fp32
+ops on the CPU, over odd shapes (lengths below one tile, not multiples of 4, channel counts
+that are not multiples of the K-chunk), every tile family and every epilogue."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vits_amd import native, packing
+from vits_amd.engine import choose_tile
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-5
+
+
+def _rand(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def _close(got, ref, what):
+    got = got.cpu()
+    assert torch.isfinite(got).all(), what
+    err = (got - ref).abs().max().item()
+    assert err <= TOL * max(1.0, ref.abs().max().item()), f"{what}: {err:.3e}"
+
+
+def _pack(w, tile, row_order=None):
+    ti = native.tile_info(tile)
+    return packing.pack_conv_weight(w, ti.ck, ti.rows_per_block, row_order).to(DEV)
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,B,L,act", [
+    (32, 32, 3, 1, 1, 1, True),          # a single sample: everything is halo
+    (32, 32, 11, 5, 2, 37, True),        # halo (50) longer than the signal
+    (64, 64, 7, 3, 3, 517, True),        # odd length: scalar staging
+    (64, 64, 7, 3, 2, 520, True),        # aligned length: 16-byte staging
+    (128, 128, 3, 5, 2, 1000, True),
+    (256, 256, 11, 1, 1, 260, True),     # two row blocks
+    (192, 512, 7, 1, 2, 45, False),      # conv_pre shape, per-item bias
+    (96, 192, 1, 1, 2, 333, False),      # c_in = 3 chunks of 32
+    (513, 192, 1, 1, 1, 50, False),      # c_in not a multiple of the chunk
+    (40, 72, 5, 2, 2, 130, True),        # neither channel count is a multiple of 32
+])
+def test_conv_store_and_residual(cin, cout, k, dil, B, L, act):
+    x = _rand(B, cin, L, seed=1)
+    w = _rand(cout, cin, k, seed=2) / (cin * k) ** 0.5
+    bias = _rand(B, cout, seed=3)
+    res = _rand(B, cout, L, seed=4)
+    pad = (k - 1) * dil // 2
+    xin = F.leaky_relu(x, 0.1) if act else x
+    ref = F.conv1d(xin, w, None, padding=pad, dilation=dil) + bias.unsqueeze(-1)
+    tile = choose_tile(cout)
+    wp = _pack(w, tile)
+    out = torch.full((B, cout, L), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), wp, out, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                  epilogue=native.EPI_STORE, bias=bias.to(DEV), bias_bstride=cout, act_in=act, in_slope=0.1)
+    _close(out, ref, "store")
+    if act:
+        out2 = torch.full((B, cout, L), float("nan"), device=DEV)
+        native.conv1d(x.to(DEV), wp, out2, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                      epilogue=native.EPI_RESID, bias=bias.to(DEV), bias_bstride=cout, res=res.to(DEV),
+                      act_in=True, in_slope=0.1)
+        _close(out2, ref + res, "residual")
+        accb = _rand(B, cout, L, seed=5)
+        out3 = accb.to(DEV).clone()
+        native.conv1d(x.to(DEV), wp, out3, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                      epilogue=native.EPI_RESID_AVG, bias=bias.to(DEV), bias_bstride=cout, res=res.to(DEV),
+                      out2=out3, act_in=True, in_slope=0.1, navg=3.0)
+        _close(out3, (accb + (ref + res)) / 3.0, "residual + accumulate + mean")
+
+
+@pytest.mark.parametrize("cin,cout,s,B,L", [(512, 256, 8, 1, 9), (256, 128, 8, 2, 131), (128, 64, 2, 2, 700),
+                                            (64, 32, 2, 1, 1030), (64, 32, 4, 2, 64)])
+def test_polyphase_upsample(cin, cout, s, B, L):
+    x = _rand(B, cin, L, seed=11)
+    wt = _rand(cin, cout, 2 * s, seed=12) / (cin * 2) ** 0.5
+    bias = _rand(cout, seed=13)
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), wt, bias, stride=s, padding=s // 2)
+    poly = packing.transposed_to_polyphase(wt, s)
+    tile = choose_tile(poly.shape[0])
+    out = torch.full((B, cout, L * s), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), _pack(poly, tile), out, c_in=cin, c_out=cout, taps=2, dilation=1, pad=1, tile=tile,
+                  epilogue=native.EPI_UPSAMPLE, bias=bias.to(DEV), act_in=True, in_slope=0.1, up_stride=s)
+    _close(out, ref, "upsample")
+
+
+@pytest.mark.parametrize("B,T,lens", [(2, 50, (50, 21)), (3, 129, (129, 1, 77)), (1, 300, (300,))])
+def test_gate_wn_and_coupling_epilogues(B, T, lens):
+    H = 192
+    mask = (torch.arange(T).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)).float()
+    x = _rand(B, H, T, seed=21)
+    w_in = _rand(2 * H, H, 5, seed=22) / (H * 5) ** 0.5
+    cond = _rand(B, 2 * H, seed=23)
+    a = F.conv1d(x, w_in, None, padding=2) + cond.unsqueeze(-1)
+    acts_ref = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])
+    acts = torch.full((B, H, T), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), _pack(w_in, native.TILE_PAIR, packing.pair_row_order(H)), acts, c_in=H, c_out=2 * H,
+                  taps=5, dilation=1, pad=2, tile=native.TILE_PAIR, epilogue=native.EPI_GATE, bias=cond.to(DEV),
+                  bias_bstride=2 * H, hidden=H)
+    _close(acts, acts_ref, "gate")
+
+    w_rs = _rand(2 * H, H, 1, seed=24) / H ** 0.5
+    b_rs = _rand(2 * H, seed=25)
+    rs = F.conv1d(acts_ref, w_rs, b_rs)
+    skip0 = _rand(B, H, T, seed=26)
+    xd, skipd = x.to(DEV).clone(), skip0.to(DEV).clone()
+    tile = choose_tile(2 * H)
+    native.conv1d(acts_ref.to(DEV), _pack(w_rs, tile), xd, c_in=H, c_out=2 * H, taps=1, dilation=1, pad=0, tile=tile,
+                  epilogue=native.EPI_WN_MID, bias=b_rs.to(DEV), res=xd, out2=skipd, mask=mask.to(DEV),
+                  first=False, hidden=H)
+    _close(xd, (x + rs[:, :H]) * mask.unsqueeze(1), "WN residual half")
+    _close(skipd, skip0 + rs[:, H:], "WN skip half")
+
+    w_last = _rand(H, H, 1, seed=27) / H ** 0.5
+    outd = torch.full((B, H, T), float("nan"), device=DEV)
+    tile = choose_tile(H)
+    native.conv1d(acts_ref.to(DEV), _pack(w_last, tile), outd, c_in=H, c_out=H, taps=1, dilation=1, pad=0, tile=tile,
+                  epilogue=native.EPI_WN_LAST, bias=b_rs[:H].to(DEV), out2=skip0.to(DEV), mask=mask.to(DEV),
+                  first=False, hidden=H)
+    _close(outd, (skip0 + F.conv1d(acts_ref, w_last, b_rs[:H])) * mask.unsqueeze(1), "WN last layer")
+
+    # coupling update written in place into a channel slice of a wider tensor
+    half = 96
+    w_post = _rand(half, H, 1, seed=28) * 0.05
+    b_post = _rand(half, seed=29) * 0.05
+    lat = _rand(B, 2 * half, T, seed=30)
+    m = F.conv1d(acts_ref, w_post, b_post) * mask.unsqueeze(1)
+    for rev in (True, False):
+        phys = lat.to(DEV).clone()
+        x1 = phys[:, half:]
+        tile = choose_tile(half)
+        native.conv1d(acts_ref.to(DEV), _pack(w_post, tile), x1, c_in=H, c_out=half, taps=1, dilation=1, pad=0,
+                      tile=tile, epilogue=native.EPI_COUPLE_REV if rev else native.EPI_COUPLE_FWD,
+                      bias=b_post.to(DEV), res=x1, mask=mask.to(DEV))
+        want = (lat[:, half:] - m) * mask.unsqueeze(1) if rev else m + lat[:, half:] * mask.unsqueeze(1)
+        _close(phys[:, half:], want, f"coupling reverse={rev}")
+        assert torch.equal(phys[:, :half].cpu(), lat[:, :half])          # the other half is untouched
+
+
+def test_speaker_linear_and_post_conv():
+    g = _rand(5, 256, seed=41)
+    w = _rand(777, 256, seed=42) / 16
+    b = _rand(777, seed=43)
+    out = torch.empty(5, 777, device=DEV)
+    native.speaker_linear(g.to(DEV), w.to(DEV), b.to(DEV), out)
+    _close(out, g @ w.t() + b, "speaker_linear")
+    for L in (1, 7, 1024, 3001):
+        x = _rand(2, 32, L, seed=44)
+        wp = _rand(1, 32, 7, seed=45) * 0.1
+        wav = torch.empty(2, 1, L, device=DEV)
+        native.post_conv_tanh(x.to(DEV), wp[0].contiguous().to(DEV), wav, 0.01)
+        _close(wav, torch.tanh(F.conv1d(F.leaky_relu(x, 0.01), wp, None, padding=3)), f"post conv L={L}")
+
+
+def test_unsupported_arguments_are_rejected_on_the_gpu_box():
+    x = torch.zeros(1, 32, 16, device=DEV)
+    wp = _pack(torch.zeros(32, 32, 3), native.TILE_M32)
+    out = torch.empty_like(x)
+    with pytest.raises(native.NativeError):      # dilation * (taps - 1) beyond the LDS halo
+        native.conv1d(x, wp, out, c_in=32, c_out=32, taps=3, dilation=40, pad=40, tile=native.TILE_M32,
+                      epilogue=native.EPI_STORE)
+    with pytest.raises(native.NativeError):      # residual epilogue without a residual
+        native.conv1d(x, wp, out, c_in=32, c_out=32, taps=3, dilation=1, pad=1, tile=native.TILE_M32,
+                      epilogue=native.EPI_RESID, act_in=True, in_slope=0.1)
+    with pytest.raises(native.NativeError):      # slope outside [0, 1]
+        native.conv1d(x, wp, out, c_in=32, c_out=32, taps=3, dilation=1, pad=1, tile=native.TILE_M32,
+                      epilogue=native.EPI_STORE, act_in=True, in_slope=1.5)
