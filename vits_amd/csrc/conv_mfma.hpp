@@ -236,12 +236,22 @@ conv_mfma_kernel(const ConvDev d)
     stg.init(d, xb, t0, lane);
     auto issue_loads = [&](int chunk) { stg.issue(d, chunk, w); };
     auto store_chunk = [&](int chunk, float* buf) { stg.store(d, chunk, buf, w, lane); };
+    issue_loads(0);          // first: the longest latency of the prologue; weights and bias follow it
 
     // ---- weight stream: one float4 per lane per 4 k-steps per row tile ----
     const float4* aptr[A_REP];
 #pragma unroll
     for (int m = 0; m < A_REP; ++m)
         aptr[m] = reinterpret_cast<const float4*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
+
+    // Weight fragments are fetched one whole tap (GPC groups) ahead: the loads for tap+1 are
+    // issued when tap starts and first touched when it ends, so a full tap of MFMAs covers
+    // them, and the in-order memory counter gives the chunk's staging loads the same cover.
+    float4 a[GPC][A_REP];
+#pragma unroll
+    for (int g = 0; g < GPC; ++g)
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) a[g][m] = aptr[m][64 * g];
 
     // Accumulators start at the bias of their row (so no epilogue adds it): register r of this
     // lane is row (r & 3) + 8 * (r >> 2) + 4 * half of the 32-row tile.
@@ -279,16 +289,6 @@ conv_mfma_kernel(const ConvDev d)
     }
     const int bcol = half * STRIDE + wn * TNW + l31 + shift + d.col0;
     
-    // Weight fragments are fetched one whole tap (GPC groups) ahead: the loads for tap+1 are
-    // issued when tap starts and first touched when it ends, so a full tap of MFMAs covers
-    // them, and the in-order memory counter gives the chunk's staging loads the same cover.
-    float4 a[GPC][A_REP];
-#pragma unroll
-    for (int g = 0; g < GPC; ++g)
-#pragma unroll
-        for (int m = 0; m < A_REP; ++m) a[g][m] = aptr[m][64 * g];
-
-    issue_loads(0);
     unsigned long long boundary_ticks = 0;      // diagnostic: time spent handing over chunks 1..n-1
     for (int chunk = 0; chunk < d.nchunk; ++chunk) {
         float* buf = lds + (chunk & 1) * (CK * STRIDE);
