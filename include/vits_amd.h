@@ -39,7 +39,7 @@ extern "C" {
  * output channels the K dimension (input-channel chunk, tap, channel pair) is laid out
  * as a linear stream of 64-lane x 4-float groups, so a wavefront fetches its A operands
  * with one coalesced 1 KiB load per 4 k-steps.  vits_amd/packing.py produces the layout;
- * vk_pack_info reports the sizes a packer must honour for a tile family.            */
+ * vk_tile_query reports the sizes a packer must honour for a tile family.           */
 typedef struct {
     int32_t ck;            /* input channels per LDS chunk (K-chunk)                  */
     int32_t rows_per_block;/* output rows (32 * A_REP * WM) handled by one workgroup  */
@@ -108,6 +108,31 @@ int64_t     vk_conv1d_lds_bytes(const vk_conv_args* a);
  * decoder.py:49-58,112,115-117 ; wn.py:70-85 ; flow.py:54,58-67 ;
  * posterior_encoder.py:52,56-59.                                                     */
 int vk_conv1d(const vk_conv_args* a, void* stream);
+
+/* ---- fused residual pair of a HiFi-GAN resblock ------------------------------------
+ *   h   = conv1(lrelu(x, slope))            taps k, dilation d, padding (k-1)*d/2
+ *   out = conv2(lrelu(h, slope)) + x        taps k, dilation 1, padding (k-1)/2
+ * (decoder.py:49-58), optionally folded into the sum over a stage's resblocks
+ * (decoder.py:119-125) through VK_EPI_RESID_ACC / VK_EPI_RESID_AVG.  The intermediate h
+ * stays in LDS.  Built for the channel widths vk_pair_query accepts (32 and 64); other
+ * widths use two vk_conv1d launches.  `out` must not overlap `x` (neighbouring
+ * workgroups read halo columns of x); `acc` may be the same view as `out`.            */
+typedef struct {
+    const float* x;       int64_t x_bstride;   int64_t x_cstride;
+    const float* w1;      const float* bias1;   /* packed for vk_pair_query's geometry */
+    const float* w2;      const float* bias2;
+    float* out;           int64_t out_bstride; int64_t out_cstride;
+    const float* acc;     int64_t acc_bstride; int64_t acc_cstride;   /* running sum or NULL */
+    int32_t batch, channels, length;
+    int32_t taps, dilation;                     /* taps odd, <= 13; (taps-1)*dilation <= 52 */
+    int32_t epilogue;                           /* VK_EPI_RESID, VK_EPI_RESID_ACC, VK_EPI_RESID_AVG */
+    float   slope, navg;
+} vk_pair_args;
+
+/* Packing geometry of the fused kernel for this channel width (VK_E_UNSUPPORTED if none);
+ * time_tile is the number of output columns a workgroup keeps.                        */
+int vk_pair_query(int channels, vk_tile_info* info);
+int vk_resblock_pair(const vk_pair_args* a, void* stream);
 
 /* out[b, o] = bias[o] + sum_i W[o, i] * g[b, i]   (speaker-conditioning 1x1 convs on
  * [B, G, 1] inputs: decoder.py:91,112 `cond`; wn.py:41-42,66 `condition_layer`).

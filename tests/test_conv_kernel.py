@@ -166,3 +166,64 @@ def test_unsupported_arguments_are_rejected_on_the_gpu_box():
     with pytest.raises(native.NativeError):      # slope outside [0, 1]
         native.conv1d(x, wp, out, c_in=32, c_out=32, taps=3, dilation=1, pad=1, tile=native.TILE_M32,
                       epilogue=native.EPI_STORE, act_in=True, in_slope=1.5)
+
+
+@pytest.mark.parametrize("ch,k,dil,B,L", [
+    (32, 3, 1, 2, 1),            # a single sample
+    (32, 11, 5, 2, 37),          # halo longer than the signal
+XX
+    (32, 7, 3, 2, 245),          # one column into the second workgroup, odd length
+    (32, 3, 5, 2, 1000),         # aligned length: 16-byte staging, several workgroups
+    (64, 11, 1, 1, 116),         # one 64-channel workgroup
+    (64, 11, 5, 2, 463),
+    (64, 3, 3, 3, 1200),
+])
+def test_fused_resblock_pair(ch, k, dil, B, L):
+    x = _rand(B, ch, L, seed=51)
+    w1 = _rand(ch, ch, k, seed=52) / (ch * k) ** 0.5
+    w2 = _rand(ch, ch, k, seed=53) / (ch * k) ** 0.5
+    b1, b2 = _rand(ch, seed=54), _rand(ch, seed=55)
+    h = F.conv1d(F.leaky_relu(x, 0.1), w1, b1, padding=(k - 1) * dil // 2, dilation=dil)
+    ref = F.conv1d(F.leaky_relu(h, 0.1), w2, b2, padding=(k - 1) // 2) + x
+    pi = native.pair_info(ch)
+    assert pi is not None
+    p1 = packing.pack_conv_weight(w1, pi.ck, pi.rows_per_block).to(DEV)
+    p2 = packing.pack_conv_weight(w2, pi.ck, pi.rows_per_block).to(DEV)
+    xd = x.to(DEV)
+    out = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.resblock_pair(xd, p1, b1.to(DEV), p2, b2.to(DEV), out, taps=k, dilation=dil,
+                         epilogue=native.EPI_RESID, slope=0.1)
+    _close(out, ref, "pair")
+    accb = _rand(B, ch, L, seed=56)
+    acc = accb.to(DEV).clone()
+    native.resblock_pair(xd, p1, b1.to(DEV), p2, b2.to(DEV), acc, taps=k, dilation=dil,
+                         epilogue=native.EPI_RESID_ACC, slope=0.1, acc=acc)
+    _close(acc, accb + ref, "pair + accumulate")
+    acc = accb.to(DEV).clone()
+    native.resblock_pair(xd, p1, b1.to(DEV), p2, b2.to(DEV), acc, taps=k, dilation=dil,
+                         epilogue=native.EPI_RESID_AVG, slope=0.1, acc=acc, navg=3.0)
+    _close(acc, (accb + ref) / 3.0, "pair + accumulate + mean")
+    # a channel-strided view of a wider tensor as input (rows not 16-byte aligned when L is odd)
+    wide = torch.zeros(B, ch + 3, L, device=DEV)
+    wide[:, 3:] = xd
+    out2 = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.resblock_pair(wide[:, 3:], p1, b1.to(DEV), p2, b2.to(DEV), out2, taps=k, dilation=dil,
+                         epilogue=native.EPI_RESID, slope=0.1)
+    _close(out2, ref, "pair on a strided view")
+
+
+def test_fused_pair_rejects_bad_arguments():
+    pi = native.pair_info(32)
+    x = torch.zeros(1, 32, 64, device=DEV)
+    wp = packing.pack_conv_weight(torch.zeros(32, 32, 3), pi.ck, pi.rows_per_block).to(DEV)
+    b = torch.zeros(32, device=DEV)
+    with pytest.raises(native.NativeError):      # output on top of the input
+        native.resblock_pair(x, wp, b, wp, b, x, taps=3, dilation=1, epilogue=native.EPI_RESID, slope=0.1)
+    with pytest.raises(native.NativeError):      # halo too long
+        native.resblock_pair(x, wp, b, wp, b, torch.empty_like(x), taps=3, dilation=30,
+                             epilogue=native.EPI_RESID, slope=0.1)
+    assert native.pair_info(128) is None
+    x128 = torch.zeros(1, 128, 64, device=DEV)
+    with pytest.raises(native.NativeError):      # width without a fused kernel
+        native.resblock_pair(x128, wp, b, wp, b, torch.empty_like(x128), taps=3, dilation=1,
+                             epilogue=native.EPI_RESID, slope=0.1)

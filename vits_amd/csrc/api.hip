@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "conv_launch.hpp"
+#include "resblock_pair.hpp"
 #include "api_internal.hpp"
 
 static thread_local char g_err[512] = "";
@@ -152,6 +153,89 @@ extern "C" int vk_conv1d(const vk_conv_args* a, void* stream)
     case VK_TILE_PAIR: e = vk_launch_tile3(a->epilogue, act, vec, d, grid, lds, s); break;
     }
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: this (tile, epilogue, act_in) combination is not built");
+    if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
+    return VK_OK;
+}
+
+static const PairGeom* pair_geom(int channels)
+{
+    if (channels == 32) return &kPair32;
+    if (channels == 64) return &kPair64;
+    return nullptr;
+}
+
+extern "C" int vk_pair_query(int channels, vk_tile_info* info)
+{
+    const PairGeom* G = pair_geom(channels);
+    if (!G || !info) return vk_fail(VK_E_UNSUPPORTED, "vk_pair_query: no fused kernel for this channel count");
+    info->ck = G->ck;
+    info->rows_per_block = 32 * G->wm;
+    info->time_tile = 32 * G->b_rep * G->wn - VK_PAIR_OVERLAP;
+    info->a_rep = 1;
+    return VK_OK;
+}
+
+extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
+{
+    if (!a) return vk_fail(VK_E_ARG, "vk_resblock_pair: null argument block");
+    if (!a->x || !a->w1 || !a->w2 || !a->out) return vk_fail(VK_E_ARG, "vk_resblock_pair: null x / w1 / w2 / out pointer");
+    if (a->batch <= 0 || a->length <= 0 || a->dilation <= 0) return vk_fail(VK_E_ARG, "vk_resblock_pair: non-positive size");
+    if (a->batch > 65535) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: batch > 65535");
+    const PairGeom* G = pair_geom(a->channels);
+    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: no fused kernel for this channel count");
+    if (a->taps < 1 || !(a->taps & 1) || a->taps - 1 > VK_PAIR_OVERLAP)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: taps must be odd and at most 13");
+    const int h2 = (a->taps - 1) / 2;
+    const int halo = (a->taps - 1) * a->dilation;
+    if (halo > 52) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: (taps-1)*dilation exceeds 52");
+    if (a->epilogue != VK_EPI_RESID && a->epilogue != VK_EPI_RESID_ACC && a->epilogue != VK_EPI_RESID_AVG)
+        return vk_fail(VK_E_ARG, "vk_resblock_pair: epilogue must be RESID, RESID_ACC or RESID_AVG");
+    if (a->epilogue != VK_EPI_RESID && !a->acc) return vk_fail(VK_E_ARG, "vk_resblock_pair: accumulate epilogue without acc");
+    if (!(a->slope >= 0.0f && a->slope <= 1.0f)) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: slope must lie in [0, 1]");
+    if (a->x_cstride < 0 || a->out_cstride < 0 || a->acc_cstride < 0) return vk_fail(VK_E_ARG, "vk_resblock_pair: negative channel stride");
+    auto span = [&](int64_t cstride) -> int64_t { return ((int64_t)(a->channels - 1) * cstride + a->length) * 4; };
+    const int64_t xb = span(a->x_cstride), ob = span(a->out_cstride), ab = a->acc ? span(a->acc_cstride) : 0;
+    if (xb > 0x7fffffffLL || ob > 0x7fffffffLL || ab > 0x7fffffffLL)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: one batch item's view spans more than 2 GiB");
+    {   // neighbouring workgroups read halo columns of x, so the output may not land on it
+        const char* x0 = (const char*)a->x;  const char* x1 = x0 + (int64_t)(a->batch - 1) * a->x_bstride * 4 + xb;
+        const char* o0 = (const char*)a->out; const char* o1 = o0 + (int64_t)(a->batch - 1) * a->out_bstride * 4 + ob;
+        if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_resblock_pair: out overlaps x");
+    }
+    const int TN = 32 * G->b_rep * G->wn;
+    PairDev q;
+    memset(&q, 0, sizeof(q));
+    vk_conv_args& c = q.c.a;
+    c.x = a->x; c.x_bstride = a->x_bstride; c.x_cstride = a->x_cstride;
+    c.w = a->w1; c.bias = a->bias1;
+    c.out = a->out; c.out_bstride = a->out_bstride; c.out_cstride = a->out_cstride;
+    c.res = a->x; c.res_bstride = a->x_bstride; c.res_cstride = a->x_cstride;
+    c.out2 = const_cast<float*>(a->acc); c.out2_bstride = a->acc_bstride; c.out2_cstride = a->acc_cstride;
+    c.batch = a->batch; c.c_in = a->channels; c.c_out = a->channels; c.length = a->length;
+    c.taps = a->taps; c.dilation = a->dilation;
+    c.pad = halo / 2 + h2;                       // column j of the first conv's output is time t0 - h2 + j
+    c.epilogue = a->epilogue; c.act_in = 1; c.in_slope = a->slope; c.navg = a->navg;
+    q.c.x_bytes = (unsigned)xb; q.c.out_bytes = (unsigned)ob; q.c.res_bytes = (unsigned)xb; q.c.out2_bytes = (unsigned)ab;
+    q.c.nchunk = a->channels / G->ck;
+    static const int no_vec = getenv("VK_NO_VEC") != nullptr;
+    const int vec = !no_vec && ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) &&
+                    (a->length % 4 == 0);
+    if (vec) {
+        const int padv = (c.pad + 3) & ~3;
+        q.c.col0 = padv - c.pad;
+        q.c.xw = (TN + halo + q.c.col0 + 3) & ~3;
+    } else {
+        q.c.col0 = 0;
+        q.c.xw = TN + halo;
+    }
+    q.c.lds_stride = TN + 68;
+    q.c.groups_per_mt = q.c.nchunk * a->taps * (G->ck / 8);
+    q.w2 = a->w2; q.bias2 = a->bias2; q.groups2 = q.c.groups_per_mt;
+    const int TNO = TN - VK_PAIR_OVERLAP;
+    dim3 grid((unsigned)((a->length + TNO - 1) / TNO), 1, (unsigned)a->batch);
+    const size_t lds = (size_t)a->channels * q.c.lds_stride * sizeof(float);
+    int e = vk_launch_pair(a->channels, a->epilogue, vec, q, grid, lds, (hipStream_t)stream);
+    if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: this combination is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
     return VK_OK;
 }

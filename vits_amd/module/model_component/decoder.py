@@ -20,6 +20,8 @@ bandwidth-bound kernel of its own.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -36,14 +38,54 @@ def get_padding(kernel_size, dilation=1):
 class ResBlockPlan:
     def __init__(self, rb: "ResNetBlock", device):
         self.pairs = []
+        # The narrowest resblocks run each (dilated conv, plain conv, residual) pair as one
+        # launch.  Measured on the MI355X the fused kernel wins at 32 channels (118 vs 96 TFLOP/s
+        # for the two-launch form) and loses at 64 (120 vs 126), so wider blocks stay unfused;
+        # VITS_AMD_PAIR_FUSION = "none" / "all" overrides the width limit.
+        mode = os.environ.get("VITS_AMD_PAIR_FUSION", "narrow")
+        pi = None if mode == "none" else native.pair_info(rb.channels)
+        k = rb.kernel_size
+        self.fused = (pi is not None and (rb.channels <= 32 or mode == "all") and k % 2 == 1 and k <= 13
+                      and all((k - 1) * d <= 52 for d in rb.dilation))
         for j, d in enumerate(rb.dilation):
             c1, c2 = rb.convs1[j], rb.convs2[j]
-            self.pairs.append((PackedConv(c1.effective_weight(), c1.bias, device, dilation=d),
-                               PackedConv(c2.effective_weight(), c2.bias, device, dilation=1)))
+            if self.fused:
+                def pk(c):
+                    return packing.pack_conv_weight(c.effective_weight().to(device), pi.ck, pi.rows_per_block)
+
+                def bs(c):
+                    return c.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+                self.pairs.append((pk(c1), bs(c1), pk(c2), bs(c2), d))
+            else:
+                self.pairs.append((PackedConv(c1.effective_weight(), c1.bias, device, dilation=d),
+                                   PackedConv(c2.effective_weight(), c2.bias, device, dilation=1)))
+        self.taps = k
+
+    def _run_fused(self, x, tmp, run_buf, final_out, final_epi, acc_in, navg):
+        # pairs ping-pong between the two scratch buffers: a pair's output may not land on its
+        # input, whose halo columns neighbouring workgroups still read
+        cur = x
+        last = len(self.pairs) - 1
+        for j, (w1, b1, w2, b2, d) in enumerate(self.pairs):
+            if j < last:
+                dst = run_buf if cur is not run_buf else tmp
+                native.resblock_pair(cur, w1, b1, w2, b2, dst, taps=self.taps, dilation=d,
+                                     epilogue=native.EPI_RESID, slope=LRELU_SLOPE)
+                cur = dst
+            else:
+                if final_out.data_ptr() == cur.data_ptr():
+                    raise native.NativeError("resblock: the output buffer aliases the last pair's input")
+                native.resblock_pair(cur, w1, b1, w2, b2, final_out, taps=self.taps, dilation=d,
+                                     epilogue=final_epi, slope=LRELU_SLOPE, acc=acc_in, navg=navg)
+        return final_out
 
     def run(self, x, tmp, run_buf, final_out, final_epi, acc_in=None, navg=1.0):
         """x -> resblock(x).  The last conv writes ``final_out`` with ``final_epi`` (plain
-        residual, or residual + accumulation over resblocks); earlier pairs update ``run_buf``."""
+        residual, or residual + accumulation over resblocks); earlier pairs update ``run_buf``
+        (and ``tmp``)."""
+        if self.fused:
+            return self._run_fused(x, tmp, run_buf, final_out, final_epi,
+                                   acc_in if final_epi != native.EPI_RESID else None, navg)
         C = x.shape[1]
         cur = x
         last = len(self.pairs) - 1
@@ -81,8 +123,8 @@ class ResNetBlock(nn.Module):
             raise native.NativeError("ResNetBlock: x_mask is never used on the inference path "
                                      "(decoder.py:122) and is not implemented in the HIP path")
         x = x.to(torch.float32).contiguous()
-        out = torch.empty_like(x)
-        return self.plan(x.device).run(x, torch.empty_like(x), out, out, native.EPI_RESID)
+        return self.plan(x.device).run(x, torch.empty_like(x), torch.empty_like(x), torch.empty_like(x),
+                                       native.EPI_RESID)
 
 
 class DecoderPlan:

@@ -45,6 +45,19 @@ class ConvArgs(C.Structure):
     ]
 
 
+class PairArgs(C.Structure):
+    """Mirror of ``vk_pair_args``."""
+    _fields_ = [
+        ("x", _fp), ("x_bstride", C.c_int64), ("x_cstride", C.c_int64),
+        ("w1", _fp), ("bias1", _fp), ("w2", _fp), ("bias2", _fp),
+        ("out", _fp), ("out_bstride", C.c_int64), ("out_cstride", C.c_int64),
+        ("acc", _fp), ("acc_bstride", C.c_int64), ("acc_cstride", C.c_int64),
+        ("batch", C.c_int32), ("channels", C.c_int32), ("length", C.c_int32),
+        ("taps", C.c_int32), ("dilation", C.c_int32), ("epilogue", C.c_int32),
+        ("slope", C.c_float), ("navg", C.c_float),
+    ]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -69,6 +82,8 @@ def lib():
         L.vk_speaker_linear.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.vk_post_conv_tanh.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_void_p]
+        L.vk_pair_query.argtypes = [C.c_int, C.POINTER(TileInfo)]
+        L.vk_resblock_pair.argtypes = [C.POINTER(PairArgs), C.c_void_p]
         if L.vk_abi_version() != 1:
             raise NativeError("libvits_amd.so ABI version mismatch")
         _lib = L
@@ -89,6 +104,18 @@ def tile_info(tile: int) -> TileInfo:
         check(lib().vk_tile_query(tile, C.byref(ti)), "vk_tile_query")
         _tile_cache[tile] = ti
     return _tile_cache[tile]
+
+
+_pair_cache = {}
+
+
+def pair_info(channels: int):
+    """Packing geometry of the fused resblock-pair kernel for this width, or None if the
+    width has no fused kernel."""
+    if channels not in _pair_cache:
+        ti = TileInfo()
+        _pair_cache[channels] = ti if lib().vk_pair_query(channels, C.byref(ti)) == 0 else None
+    return _pair_cache[channels]
 
 
 def stream_ptr(device) -> int:
@@ -188,6 +215,29 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     sp = stream_ptr(x.device)
     detail = f"B{x.shape[0]} L{x.shape[2]} {c_in}->{rows} k{taps} d{dilation}"
     check(_timed(family, flops, 0.0, x.device, lambda: L.vk_conv1d(C.byref(a), sp), detail), "vk_conv1d")
+
+
+def resblock_pair(x, w1, bias1, w2, bias2, out, *, taps, dilation, epilogue, slope, acc=None, navg=1.0):
+    """out = conv2(lrelu(conv1(lrelu(x)))) + x (+ acc) in one launch; ``out`` must not alias ``x``."""
+    assert x.is_cuda, "the HIP path needs device tensors"
+    a = PairArgs()
+    a.x, a.x_bstride, a.x_cstride = _view(x)
+    a.w1, a.w2 = w1.data_ptr(), w2.data_ptr()
+    a.bias1 = bias1.data_ptr() if bias1 is not None else None
+    a.bias2 = bias2.data_ptr() if bias2 is not None else None
+    a.out, a.out_bstride, a.out_cstride = _view(out)
+    if acc is not None:
+        a.acc, a.acc_bstride, a.acc_cstride = _view(acc)
+    a.batch, a.channels, a.length = x.shape
+    a.taps, a.dilation, a.epilogue = taps, dilation, epilogue
+    a.slope, a.navg = slope, navg
+    ch = x.shape[1]
+    flops = 2.0 * x.shape[0] * x.shape[2] * ch * ch * taps * 2
+    family = f"resblock_pair[c{ch},{_EPI_NAMES[epilogue]}]"
+    L, sp = lib(), stream_ptr(x.device)
+    detail = f"B{x.shape[0]} L{x.shape[2]} c{ch} k{taps} d{dilation}"
+    check(_timed(family, flops, 0.0, x.device, lambda: L.vk_resblock_pair(C.byref(a), sp), detail),
+          "vk_resblock_pair")
 
 
 def speaker_linear(g, w, bias, out):
