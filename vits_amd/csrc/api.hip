@@ -116,7 +116,9 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
         d->col0 = 0;
         d->xw = TN + halo;
     }
-    d->lds_stride = TN + 68;              // compile-time constant of the kernel: tile + halo (<= 64) + alignment slack
+    d->lds_stride = TN + 64;              // compile-time constant of the kernel
+    if (d->xw > d->lds_stride)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: time tile + halo does not fit the staged LDS row");
     d->groups_per_mt = d->nchunk * a->taps * (G.ck / 8);
     static const int dbg = getenv("VK_DEBUG_SKIP") ? atoi(getenv("VK_DEBUG_SKIP")) : 0;
     d->dbg = dbg;
@@ -228,7 +230,7 @@ extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
         q.c.col0 = 0;
         q.c.xw = TN + halo;
     }
-    q.c.lds_stride = TN + 68;
+    q.c.lds_stride = TN + 64;
     q.c.groups_per_mt = q.c.nchunk * a->taps * (G->ck / 8);
     q.w2 = a->w2; q.bias2 = a->bias2; q.groups2 = q.c.groups_per_mt;
     const int TNO = TN - VK_PAIR_OVERLAP;

@@ -7,10 +7,10 @@ struct TileGeom { int a_rep, b_rep, wm, wn, ck; };
 
 // VK_TILE_M128, VK_TILE_M64, VK_TILE_M32, VK_TILE_PAIR
 static constexpr TileGeom kTiles[VK_TILE_COUNT] = {
-    {1, 4, 4, 1, 32},
+    {1, 4, 4, 1, 16},
     {1, 4, 2, 2, 16},
     {1, 4, 1, 4, 16},
-    {2, 2, 2, 2, 32},
+    {2, 2, 2, 2, 16},
 };
 
 // Returns hipSuccess / a HIP error, or -1 when (epilogue, act_in) is not built for the tile.

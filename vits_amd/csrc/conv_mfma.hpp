@@ -194,7 +194,7 @@ __device__ __forceinline__ void vk_stamp(const ConvDev& d, int slot)
 }
 
 template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT, bool VEC>
-__global__ void __launch_bounds__(64 * WM * WN, (512 / (64 * WM * WN)) > 0 ? (512 / (64 * WM * WN)) : 1)
+__global__ void __launch_bounds__(64 * WM * WN, (EPI == VK_EPI_SAMPLE) ? 2 : ((WM == 1 && WN == 4) ? 3 : 4))   // second figure: waves per SIMD the register budget must allow
 conv_mfma_kernel(const ConvDev d)
 {
     constexpr int NW  = WM * WN;
@@ -222,7 +222,7 @@ conv_mfma_kernel(const ConvDev d)
     const int t0   = blockIdx.x * TN;
     const int mt0  = (blockIdx.y * WM + wm) * A_REP;   // first packed 32-row tile of this wave
     const int L    = p.length;
-    constexpr int STRIDE = TN + 68;          // floats between staged rows (>= tile + 64-column halo + alignment slack)
+    constexpr int STRIDE = TN + 64;          // floats between staged rows (the host checks that tile + halo fits)
 
     const float* xb = p.x + (int64_t)b * p.x_bstride;
     vk_stamp(d, 0);

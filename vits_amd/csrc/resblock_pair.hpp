@@ -37,7 +37,7 @@ resblock_pair_kernel(const PairDev q)
     constexpr int GPC = CK / 8;
     constexpr int C   = 32 * WM;                  // channels
     constexpr int NCH = C / CK;                   // K-chunks of either conv
-    constexpr int STRIDE = TN + 68;
+    constexpr int STRIDE = TN + 64;
     static_assert(C % CK == 0 && CK % NW == 0 && CK % 8 == 0, "chunking");
     static_assert(TN % 64 == 0, "time tile must be a multiple of the wave width");
     static_assert(NCH <= 2, "every chunk of x keeps an LDS buffer of its own");
