@@ -171,10 +171,10 @@ def test_unsupported_arguments_are_rejected_on_the_gpu_box():
 @pytest.mark.parametrize("ch,k,dil,B,L", [
     (32, 3, 1, 2, 1),            # a single sample
     (32, 11, 5, 2, 37),          # halo longer than the signal
-XX
-    (32, 7, 3, 2, 245),          # one column into the second workgroup, odd length
-    (32, 3, 5, 2, 1000),         # aligned length: 16-byte staging, several workgroups
-    (64, 11, 1, 1, 116),         # one 64-channel workgroup
+    (32, 7, 3, 1, 500),          # exactly one workgroup's worth of outputs
+    (32, 7, 3, 2, 501),          # one column into the second workgroup, odd length
+    (32, 3, 5, 2, 2000),         # aligned length: 16-byte staging, several workgroups
+    (64, 11, 1, 1, 180),         # one 64-channel workgroup
     (64, 11, 5, 2, 463),
     (64, 3, 3, 3, 1200),
 ])
