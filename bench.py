@@ -164,6 +164,10 @@ def main():
     if rank == 0:
         fam = timer.summary()
         name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        traffic = None      # HBM bytes per launch from the committed counter passes of this same workload
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+        if args.workload == "batch" and (B, T) == (16, 862) and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["by_family"].get(name, {}).get("hbm_bytes_per_launch")
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         total_ms = sum(d["ms"] for d in fam.values())
         total_flops = sum(d["flops"] for d in fam.values())
@@ -183,7 +187,9 @@ def main():
                        "frames": T if args.workload == "batch" else None, "sample_rate": SAMPLE_RATE,
                        "parallelism": f"utterance-sharded x{world}, no hot-path collective"},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes "
+                                         "stored in profiles/hbm_traffic.json" if traffic else None,
                          "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                          "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
                          "share_of_device_time": dom["ms"] / total_ms,
