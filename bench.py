@@ -33,6 +33,8 @@ from vits_amd.module.vits_generator import HotPathGenerator          # noqa: E40
 
 SAMPLE_RATE = 22050
 HOP = 256
+BF16_MATRIX_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak
+HBM_PEAK_GBS = 8000.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 SEED = 999
 
@@ -48,6 +50,8 @@ def parse():
                     help="batch: fixed batch per GPU (weak scaling, the headline); corpus: a length-bucketed "
                          "synthetic corpus sharded over the ranks (strong scaling)")
     ap.add_argument("--corpus", type=int, default=4096, help="utterances in the corpus workload")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="matrix-core input precision; fp32 is the <= 1e-4 parity path and the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
@@ -84,6 +88,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from vits_amd import engine
+    engine.set_precision(args.precision)
     dist = None
     if world > 1 or "RANK" in os.environ:           # launched by torch.distributed.run, any world size
         import torch.distributed as dist
@@ -171,12 +177,38 @@ def main():
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         total_ms = sum(d["ms"] for d in fam.values())
         total_flops = sum(d["flops"] for d in fam.values())
+        if args.precision == "bf16":
+            # bf16 matrix inputs: the convolutions turn HBM-bound (fp32 tensors in memory)
+            t_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
+            t_mfma = dom["flops"] / (BF16_MATRIX_PEAK_TFLOPS * 1e12)
+            if t_hbm >= t_mfma:
+                gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": None}
+            else:
+                roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": BF16_MATRIX_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / BF16_MATRIX_PEAK_TFLOPS, "traffic": None}
+            roof.update({"launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                         "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                         "mb_per_launch": dom["bytes"] / dom["launches"] / 1e6,
+                         "share_of_device_time": dom["ms"] / total_ms,
+                         "all_kernels_tflops": total_flops / (total_ms * 1e-3) / 1e12})
+        roof_fp32 = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes "
+                                         "stored in profiles/hbm_traffic.json" if traffic else None,
+                         "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                         "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                         "share_of_device_time": dom["ms"] / total_ms,
+                         "all_kernels_tflops": total_flops / (total_ms * 1e-3) / 1e12}
         line = {
             "metric": "audio seconds generated/sec (RTF^-1), 10 s utterances",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak" if args.workload == "batch" else "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16 matrix inputs, f32 accumulate, f32 tensors",
+            "data": "synthetic",
             "config": {"workload": ("reverse flow + HiFi-GAN decoder (TTS hot path), "
                                     f"batch {B} x {T} frames ({T * HOP / SAMPLE_RATE:.2f} s) per GPU, 100 speakers, "
                                     "random-init weights") if args.workload == "batch" else
@@ -186,14 +218,7 @@ def main():
                        "batch_per_gpu": B if args.workload == "batch" else None,
                        "frames": T if args.workload == "batch" else None, "sample_rate": SAMPLE_RATE,
                        "parallelism": f"utterance-sharded x{world}, no hot-path collective"},
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes "
-                                         "stored in profiles/hbm_traffic.json" if traffic else None,
-                         "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
-                         "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
-                         "share_of_device_time": dom["ms"] / total_ms,
-                         "all_kernels_tflops": total_flops / (total_ms * 1e-3) / 1e12},
+            "roofline": roof if args.precision == "bf16" else roof_fp32,
             "per_gpu_value": value / world,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 1
+#define VK_ABI_VERSION 2
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -45,7 +45,19 @@ typedef struct {
     int32_t rows_per_block;/* output rows (32 * A_REP * WM) handled by one workgroup  */
     int32_t time_tile;     /* output columns (time steps) handled by one workgroup    */
     int32_t a_rep;         /* consecutive 32-row tiles owned by one wavefront         */
+    int32_t ck_bf16;       /* K-chunk of the bf16-input kernels (VK_PREC_BF16)         */
 } vk_tile_info;
+
+/* Matrix-core input precision (vk_conv_args.precision).  Activations, bias, residuals and
+ * outputs are fp32 in memory either way and accumulation is fp32.
+ *   VK_PREC_F32   v_mfma_f32_32x32x2_f32: exact fp32 products (the <= 1e-4 parity path);
+ *                 weights packed as fp32 groups [mt][chunk][tap][g][64 lanes][4].
+ *   VK_PREC_BF16  v_mfma_f32_32x32x16_bf16: activations (after the leaky-ReLU) and weights are
+ *                 rounded to bf16 (nearest even); weights packed as bf16
+ *                 [mt][chunk][tap][kstep][64 lanes][8], lane l holding row l & 31, channels
+ *                 chunk*ck_bf16 + 16*kstep + 8*(l >> 5) .. +7.                                */
+#define VK_PREC_F32   0
+#define VK_PREC_BF16  1
 
 /* Tile families (vk_conv_args.tile). */
 #define VK_TILE_M128  0   /* 128 rows x 128 cols, 4 waves split rows        (C_out >= 128) */
@@ -93,6 +105,7 @@ typedef struct {
     int32_t hidden;       /* VK_EPI_WN_MID: rows < hidden are the residual half */
     int32_t up_stride;    /* VK_EPI_UPSAMPLE: stride S (kernel 2S, padding S/2) */
     float   navg;         /* VK_EPI_RESID_AVG divisor */
+    int32_t precision;    /* VK_PREC_F32 or VK_PREC_BF16 (selects the packed weight format too) */
 } vk_conv_args;
 
 int         vk_abi_version(void);

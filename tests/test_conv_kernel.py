@@ -227,3 +227,75 @@ def test_fused_pair_rejects_bad_arguments():
     with pytest.raises(native.NativeError):      # width without a fused kernel
         native.resblock_pair(x128, wp, b, wp, b, torch.empty_like(x128), taps=3, dilation=1,
                              epilogue=native.EPI_RESID, slope=0.1)
+
+
+# ---- bf16 matrix-core inputs: the kernel must equal an fp32 convolution of the bf16-rounded
+# ---- operands (products of bf16 values are exact in fp32; only the summation order differs)
+def _r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _pack16(w, tile, row_order=None):
+    ti = native.tile_info(tile)
+    return packing.pack_conv_weight_bf16(w, ti.ck_bf16, ti.rows_per_block, row_order).to(DEV)
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,B,L,act", [
+    (32, 32, 3, 1, 1, 1, True),
+    (32, 32, 11, 5, 2, 37, True),
+    (64, 64, 7, 3, 3, 517, True),
+    (128, 128, 3, 5, 2, 1000, True),
+    (256, 256, 11, 1, 1, 260, True),
+    (192, 512, 7, 1, 2, 45, False),
+    (513, 192, 1, 1, 1, 50, False),      # c_in not a multiple of the chunk
+    (40, 72, 5, 2, 2, 130, True),
+])
+def test_bf16_conv_store_and_residual(cin, cout, k, dil, B, L, act):
+    x = _rand(B, cin, L, seed=61)
+    w = _rand(cout, cin, k, seed=62) / (cin * k) ** 0.5
+    bias = _rand(B, cout, seed=63)
+    res = _rand(B, cout, L, seed=64)
+    pad = (k - 1) * dil // 2
+    xin = _r16(F.leaky_relu(x, 0.1) if act else x)
+    ref = F.conv1d(xin, _r16(w), None, padding=pad, dilation=dil) + bias.unsqueeze(-1)
+    tile = choose_tile(cout)
+    wp = _pack16(w, tile)
+    out = torch.full((B, cout, L), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), wp, out, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                  epilogue=native.EPI_STORE, bias=bias.to(DEV), bias_bstride=cout, act_in=act, in_slope=0.1)
+    _close(out, ref, "bf16 store")
+    if act:
+        accb = _rand(B, cout, L, seed=65)
+        out3 = accb.to(DEV).clone()
+        native.conv1d(x.to(DEV), wp, out3, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                      epilogue=native.EPI_RESID_AVG, bias=bias.to(DEV), bias_bstride=cout, res=res.to(DEV),
+                      out2=out3, act_in=True, in_slope=0.1, navg=3.0)
+        _close(out3, (accb + (ref + res)) / 3.0, "bf16 residual + accumulate + mean")
+
+
+@pytest.mark.parametrize("cin,cout,s,B,L", [(512, 256, 8, 1, 9), (128, 64, 2, 2, 700), (64, 32, 2, 1, 1030)])
+def test_bf16_polyphase_upsample(cin, cout, s, B, L):
+    x = _rand(B, cin, L, seed=71)
+    wt = _rand(cin, cout, 2 * s, seed=72) / (cin * 2) ** 0.5
+    bias = _rand(cout, seed=73)
+    ref = F.conv_transpose1d(_r16(F.leaky_relu(x, 0.1)), _r16(wt), bias, stride=s, padding=s // 2)
+    poly = packing.transposed_to_polyphase(wt, s)
+    tile = choose_tile(poly.shape[0])
+    out = torch.full((B, cout, L * s), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), _pack16(poly, tile), out, c_in=cin, c_out=cout, taps=2, dilation=1, pad=1, tile=tile,
+                  epilogue=native.EPI_UPSAMPLE, bias=bias.to(DEV), act_in=True, in_slope=0.1, up_stride=s)
+    _close(out, ref, "bf16 upsample")
+
+
+def test_bf16_gate_epilogue():
+    B, T, H = 2, 131, 192
+    x = _rand(B, H, T, seed=81)
+    w_in = _rand(2 * H, H, 5, seed=82) / (H * 5) ** 0.5
+    cond = _rand(B, 2 * H, seed=83)
+    a = F.conv1d(_r16(x), _r16(w_in), None, padding=2) + cond.unsqueeze(-1)
+    ref = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])
+    acts = torch.full((B, H, T), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), _pack16(w_in, native.TILE_PAIR, packing.pair_row_order(H)), acts, c_in=H, c_out=2 * H,
+                  taps=5, dilation=1, pad=2, tile=native.TILE_PAIR, epilogue=native.EPI_GATE, bias=cond.to(DEV),
+                  bias_bstride=2 * H, hidden=H)
+    _close(acts, ref, "bf16 gate")

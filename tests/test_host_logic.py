@@ -132,7 +132,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(native.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/vits_amd.h but not exported"
-    assert native.lib().vk_abi_version() == 1
+    assert native.lib().vk_abi_version() == 2
 
 
 def test_argument_validation_without_gpu():

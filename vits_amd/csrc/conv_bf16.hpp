@@ -1,0 +1,207 @@
+// The same implicit-GEMM convolution with bf16 matrix-core inputs and fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16).  Activations stay fp32 in HBM; they are activated (leaky-ReLU)
+// and rounded to bf16 (round to nearest even) while the tile is staged into LDS, weights are
+// pre-rounded and pre-packed on the host.  Everything after the accumulators - bias, residuals,
+// gates, coupling updates, stores - is the fp32 epilogue of conv_mfma.hpp.
+//
+// One matrix instruction contracts 16 input channels: lane l supplies 8 consecutive channels
+// (8 * (l >> 5) ..) of row / column l & 31.  The staged tile is therefore channel-minor,
+//   lds[column][channel within chunk]   (bf16, PITCH bytes per column),
+// so a B fragment is one 16-byte LDS read per lane and a tap is a column offset.
+// Staging transposes on the way in: a lane owns one column, loads 8 channels of it (each load
+// is contiguous across the wave) and writes them with one 16-byte LDS store.
+#pragma once
+#include "conv_mfma.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT>
+__global__ void __launch_bounds__(64 * WM * WN, 2)
+conv_bf16_kernel(const ConvDev d)
+{
+    constexpr int NW  = WM * WN;
+    constexpr int TNW = 32 * B_REP;
+    constexpr int TN  = TNW * WN;
+    constexpr int NJ  = TN / 64 + 1;            // 64-column pieces per staged tile (halo <= 64)
+    constexpr int CG  = CK / 8;                 // groups of 8 channels per chunk
+    constexpr int NP  = NJ * CG;                // (piece, group) staging units per chunk
+    constexpr int NI  = (NP + NW - 1) / NW;     // units per wave
+    constexpr int KS  = CK / 16;                // matrix instructions per tap per chunk
+    constexpr int PITCH = CK * 2 + 16;          // bytes between staged columns (odd multiple of 16: conflict-free)
+    constexpr int BUF = (TN + 64) * PITCH;      // bytes per staging buffer
+    static_assert(CK % 16 == 0, "a matrix instruction contracts 16 channels");
+    static_assert(TN % 64 == 0, "time tile must be a multiple of the wave width");
+    constexpr bool PAIR = (EPI == VK_EPI_GATE || EPI == VK_EPI_SAMPLE);
+    static_assert(!PAIR || (A_REP % 2 == 0), "paired epilogues need an even number of row tiles per wave");
+
+    extern __shared__ __attribute__((aligned(16))) char lds8[];
+
+    const vk_conv_args& p = d.a;
+    const int lane = threadIdx.x & 63;
+    const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm   = w % WM;
+    const int wn   = w / WM;
+    const int half = lane >> 5;
+    const int l31  = lane & 31;
+    const int b    = blockIdx.z;
+    const int t0   = blockIdx.x * TN;
+    const int mt0  = (blockIdx.y * WM + wm) * A_REP;
+    const int L    = p.length;
+
+    const float* xb = p.x + (int64_t)b * p.x_bstride;
+    const __amdgpu_buffer_rsrc_t rx = vk_rsrc(xb, d.x_bytes);
+
+    // ---- staging units of this wave: unit id = w + NW * i -> (channel group, 64-column piece) ----
+    int  u_voff[NI];        // clamped byte offset of this lane's column within a row of x
+    int  u_lds[NI];         // byte offset of this lane's 16-byte slot within a staging buffer
+    int  u_cg[NI];          // channel group (wave-uniform)
+    bool u_in[NI];          // this lane's column lies inside [0, L)
+    bool u_on[NI];          // wave-uniform: the unit exists and its piece overlaps the staged width
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int pid = w + NW * i;
+        const int cg = pid / NJ, piece = pid - cg * NJ;
+        const int col = piece * 64 + lane;
+        const int t = t0 - p.pad + (col < d.xw ? col : d.xw - 1);     // lanes past the staged width re-read its last column
+        u_cg[i] = cg;
+        u_on[i] = (pid < NP) && (piece * 64 < d.xw);
+        u_voff[i] = 4 * (t < 0 ? 0 : (t >= L ? L - 1 : t));
+        u_in[i] = (t >= 0) && (t < L);
+        u_lds[i] = col * PITCH + cg * 16;
+    }
+    float st[NI][8];
+    auto issue_loads = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (u_on[i]) {                                           // wave-uniform
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const int c = chunk * CK + u_cg[i] * 8 + c8;
+                    const int soff = (int)((c < p.c_in ? c : 0) * p.x_cstride * 4);
+                    st[i][c8] = vk_bld(rx, u_voff[i], soff);
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](int chunk, char* buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (u_on[i]) {
+                bf16x8 o;
+#pragma unroll
+                for (int c8 = 0; c8 < 8; c8 += 2) {
+                    const int c = chunk * CK + u_cg[i] * 8 + c8;
+                    float v0 = (u_in[i] && c < p.c_in) ? st[i][c8] : 0.0f;
+                    float v1 = (u_in[i] && c + 1 < p.c_in) ? st[i][c8 + 1] : 0.0f;
+                    if (ACT) { v0 = vk_lrelu(v0, p.in_slope); v1 = vk_lrelu(v1, p.in_slope); }
+                    const f32x2 pr = {v0, v1};
+                    const bf16x2 q = __builtin_convertvector(pr, bf16x2);
+                    o[c8] = q[0]; o[c8 + 1] = q[1];
+                }
+                *reinterpret_cast<bf16x8*>(buf + u_lds[i]) = o;
+            }
+        }
+    };
+    issue_loads(0);
+
+    // ---- weight stream: one 16-byte fragment per lane per matrix instruction ----
+    const bf16x8* aptr[A_REP];
+#pragma unroll
+    for (int m = 0; m < A_REP; ++m)
+        aptr[m] = reinterpret_cast<const bf16x8*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
+    bf16x8 a[KS][A_REP];
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) a[k][m] = aptr[m][64 * k];
+
+    // accumulators start at the bias of their row
+    f32x16 acc[A_REP][B_REP];
+    {
+        const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
+        const int rows_total_b = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) {
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                int brow = prow;
+                if (PAIR) brow = ((m & 1) ? p.hidden : 0) + 32 * ((mt0 + m) >> 1) + (prow & 31);
+                if (EPI == VK_EPI_UPSAMPLE) brow = prow % p.c_out;
+                bv[r] = 0.0f;
+                if (biasb != nullptr) {
+                    const float raw = biasb[prow < rows_total_b ? brow : 0];
+                    bv[r] = prow < rows_total_b ? raw : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = bv[r];
+        }
+    }
+
+    int shift = 0;          // transposed conv: upper phases read one column later
+    if (EPI == VK_EPI_UPSAMPLE) {
+        const int phase = (mt0 * 32) / p.c_out;
+        shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
+    }
+    const int bcol = (wn * TNW + l31 + shift) * PITCH + half * 16;
+    const int tap_step = p.dilation * PITCH;
+
+    for (int chunk = 0; chunk < d.nchunk; ++chunk) {
+        char* buf = lds8 + (chunk & 1) * BUF;
+        store_chunk(chunk, buf);
+        __syncthreads();
+        if (chunk + 1 < d.nchunk) issue_loads(chunk + 1);
+
+        const char* bt = buf + bcol;
+        bf16x8 bf[B_REP];
+#pragma unroll
+        for (int n = 0; n < B_REP; ++n) bf[n] = *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH);
+#pragma unroll 1
+        for (int tap = 0; tap < p.taps; ++tap) {
+            const char* bt_next = (tap + 1 < p.taps) ? bt + tap_step : buf + bcol;
+            bf16x8 a_nxt[KS][A_REP];
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = aptr[m][64 * (KS + k)];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                bf16x8 bn[B_REP];
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n)
+                    bn[n] = (k + 1 < KS) ? *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH + (k + 1) * 32)
+                                         : *reinterpret_cast<const bf16x8*>(bt_next + n * 32 * PITCH);
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+                    for (int n = 0; n < B_REP; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k][m], bf[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
+            }
+            bt = bt_next;
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * KS;
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a[k][m] = a_nxt[k][m];
+        }
+    }
+
+    conv_epilogue<A_REP, B_REP, EPI>(d, acc, b, t0, mt0, wn, half, l31);
+}
+
+// channels per staged chunk of the bf16 kernels, by tile family
+static constexpr int kBf16Ck[VK_TILE_COUNT] = {32, 32, 16, 32};
+
+int vk_launch_bf16_tile0(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_bf16_tile1(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_bf16_tile2(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_bf16_tile3(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);

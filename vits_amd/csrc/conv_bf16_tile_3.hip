@@ -1,0 +1,26 @@
+// bf16-input instantiations of tile family 3.
+#include "conv_launch.hpp"
+#include "conv_bf16.hpp"
+
+#define VK_BF16_CASE(EPI, ACT)                                                                   \
+    if (epi == (EPI) && act == (ACT)) {                                                          \
+        auto k = conv_bf16_kernel<G.a_rep, G.b_rep, G.wm, G.wn, CKB, (EPI), (ACT) != 0>;         \
+        static size_t lds_allowed = 65536;                                                       \
+        if (lds > lds_allowed) {                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return (int)e;                                                  \
+            lds_allowed = 160 * 1024;                                                            \
+        }                                                                                        \
+        hipLaunchKernelGGL(k, grid, dim3(64 * G.wm * G.wn), lds, s, d);                          \
+        return (int)hipGetLastError();                                                           \
+    }
+
+int vk_launch_bf16_tile3(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s)
+{
+    constexpr TileGeom G = kTiles[3];
+    constexpr int CKB = kBf16Ck[3];
+    VK_BF16_CASE(VK_EPI_GATE, 0)
+    VK_BF16_CASE(VK_EPI_SAMPLE, 0)
+    return -1;
+}

@@ -193,170 +193,16 @@ __device__ __forceinline__ void vk_stamp(const ConvDev& d, int slot)
     }
 }
 
-template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT, bool VEC>
-__global__ void __launch_bounds__(64 * WM * WN, (EPI == VK_EPI_SAMPLE) ? 2 : ((WM == 1 && WN == 4) ? 3 : 4))   // second figure: waves per SIMD the register budget must allow
-conv_mfma_kernel(const ConvDev d)
+// Fused epilogue of one wave's accumulators (A_REP x B_REP tiles of 32 x 32, rows starting at
+// packed tile mt0, columns at t0 + wn * 32 * B_REP); shared by every main-loop variant.
+template <int A_REP, int B_REP, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvDev& d, f32x16 (&acc)[A_REP][B_REP], int b, int t0, int mt0,
+                                              int wn, int half, int l31)
 {
-    constexpr int NW  = WM * WN;
-    constexpr int TNW = 32 * B_REP;          // time steps per wave
-    constexpr int TN  = TNW * WN;            // time steps per workgroup
-    constexpr int NJ  = TN / 64 + 1;         // 64-column pieces per staged row (halo <= 64)
-    constexpr int NJ4 = (TN + 70 + 255) / 256;   // 64-lane x float4 pieces per staged row (vector staging)
-    constexpr int RPW = CK / NW;             // staged rows per wave per chunk
-    constexpr int GPC = CK / 8;              // weight groups per (chunk, tap)
-    static_assert(CK % NW == 0 && CK % 8 == 0, "chunk must split over waves and k-groups");
-    static_assert(TN % 64 == 0, "time tile must be a multiple of the wave width");
+    constexpr int TNW = 32 * B_REP;
     constexpr bool PAIR = (EPI == VK_EPI_GATE || EPI == VK_EPI_SAMPLE);
-    static_assert(!PAIR || (A_REP % 2 == 0), "paired epilogues need an even number of row tiles per wave");
-
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
     const vk_conv_args& p = d.a;
-    const int lane = threadIdx.x & 63;
-    const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm   = w % WM;
-    const int wn   = w / WM;
-    const int half = lane >> 5;
-    const int l31  = lane & 31;
-    const int b    = blockIdx.z;
-    const int t0   = blockIdx.x * TN;
-    const int mt0  = (blockIdx.y * WM + wm) * A_REP;   // first packed 32-row tile of this wave
-    const int L    = p.length;
-    constexpr int STRIDE = TN + 64;          // floats between staged rows (the host checks that tile + halo fits)
-
-    const float* xb = p.x + (int64_t)b * p.x_bstride;
-    vk_stamp(d, 0);
-
-    // ---- staging: global -> registers (issued early) -> LDS (written after the barrier) ----
-    // The column layout of the staged tile is the same for every row and chunk of the tile, so
-    // load offsets and in-range bits are computed once (see the stager structs above).
-    using Stager = typename std::conditional<VEC, VectorStager<RPW, NJ4, NW, CK, ACT>,
-                                                  ScalarStager<RPW, NJ, NW, CK, ACT>>::type;
-    Stager stg;
-    stg.init(d, xb, t0, lane);
-    auto issue_loads = [&](int chunk) { stg.issue(d, chunk, w); };
-    auto store_chunk = [&](int chunk, float* buf) { stg.store(d, chunk, buf, w, lane); };
-    issue_loads(0);          // first: the longest latency of the prologue; weights and bias follow it
-
-    // ---- weight stream: one float4 per lane per 4 k-steps per row tile ----
-    const float4* aptr[A_REP];
-#pragma unroll
-    for (int m = 0; m < A_REP; ++m)
-        aptr[m] = reinterpret_cast<const float4*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
-
-    // Weight fragments are fetched one whole tap (GPC groups) ahead: the loads for tap+1 are
-    // issued when tap starts and first touched when it ends, so a full tap of MFMAs covers
-    // them, and the in-order memory counter gives the chunk's staging loads the same cover.
-    float4 a[GPC][A_REP];
-#pragma unroll
-    for (int g = 0; g < GPC; ++g)
-#pragma unroll
-        for (int m = 0; m < A_REP; ++m) a[g][m] = aptr[m][64 * g];
-
-    // Accumulators start at the bias of their row (so no epilogue adds it): register r of this
-    // lane is row (r & 3) + 8 * (r >> 2) + 4 * half of the 32-row tile.
-    f32x16 acc[A_REP][B_REP];
-    {
-        const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
-        const int rows_total_b = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
-#pragma unroll
-        for (int m = 0; m < A_REP; ++m) {
-            float bv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int prow = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // packed row
-                int brow = prow;                                                        // bias index
-                if (PAIR) brow = ((m & 1) ? p.hidden : 0) + 32 * ((mt0 + m) >> 1) + (prow & 31);
-                if (EPI == VK_EPI_UPSAMPLE) brow = prow % p.c_out;
-                bv[r] = 0.0f;
-                if (biasb != nullptr) {                      // wave-uniform
-                    const float raw = biasb[prow < rows_total_b ? brow : 0];
-                    bv[r] = prow < rows_total_b ? raw : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < B_REP; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = bv[r];
-        }
-    }
-
-    // transposed conv: row tiles of the upper phases read the staged tile one column later
-    int shift = 0;
-    if (EPI == VK_EPI_UPSAMPLE) {
-        const int phase = (mt0 * 32) / p.c_out;
-        shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
-    }
-    const int bcol = half * STRIDE + wn * TNW + l31 + shift + d.col0;
-    
-    unsigned long long boundary_ticks = 0;      // diagnostic: time spent handing over chunks 1..n-1
-    for (int chunk = 0; chunk < d.nchunk; ++chunk) {
-        float* buf = lds + (chunk & 1) * (CK * STRIDE);
-        unsigned long long tb0 = 0;
-        if (d.stamps) tb0 = __builtin_amdgcn_s_memrealtime();
-        if (!(d.dbg & 4) || chunk == 0) store_chunk(chunk, buf);
-        if (!(d.dbg & 8) || chunk == 0) __syncthreads();
-        if (chunk == 0) vk_stamp(d, 1);
-        else if (d.stamps) boundary_ticks += __builtin_amdgcn_s_memrealtime() - tb0;
-        if (chunk + 1 < d.nchunk && !(d.dbg & 4)) issue_loads(chunk + 1);
-        if (d.dbg & 2) continue;
-
-        // k-steps walk channel pairs within a tap, then taps; the B fragments of the next
-        // k-step are read from LDS before the current k-step's MFMAs are issued.  Within a tap
-        // every read is the tap's base address plus a compile-time offset.
-        const float* bt = buf + bcol;
-        float bf[B_REP];
-#pragma unroll
-        for (int n = 0; n < B_REP; ++n) bf[n] = bt[32 * n];
-#pragma unroll 1
-        for (int tap = 0; tap < p.taps; ++tap) {
-            const float* bt_next = (tap + 1 < p.taps) ? bt + p.dilation : buf + bcol;   // chunk end: harmless re-read
-            float4 a_nxt[GPC][A_REP];
-#pragma unroll
-            for (int g = 0; g < GPC; ++g)
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m) a_nxt[g][m] = aptr[m][64 * (GPC + g)];
-            __builtin_amdgcn_sched_group_barrier(0x020, GPC * A_REP, 0);
-#pragma unroll
-            for (int g = 0; g < GPC; ++g) {
-                float4 a_cur[A_REP];
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m) a_cur[m] = a[g][m];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    constexpr int KSTEPS = 4 * GPC;
-                    const int ks = 4 * g + e;
-                    float bn[B_REP];
-#pragma unroll
-                    for (int n = 0; n < B_REP; ++n)
-                        bn[n] = (ks + 1 < KSTEPS) ? bt[2 * (ks + 1) * STRIDE + 32 * n] : bt_next[32 * n];
-#pragma unroll
-                    for (int m = 0; m < A_REP; ++m) {
-                        const float av = (e == 0) ? a_cur[m].x : (e == 1) ? a_cur[m].y
-                                       : (e == 2) ? a_cur[m].z : a_cur[m].w;
-#pragma unroll
-                        for (int n = 0; n < B_REP; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc[m][n], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
-                    __builtin_amdgcn_sched_group_barrier(0x100, (B_REP + 1) / 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, A_REP * B_REP, 0);
-                }
-            }
-            bt = bt_next;
-#pragma unroll
-            for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * GPC;
-#pragma unroll
-            for (int g = 0; g < GPC; ++g)
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m) a[g][m] = a_nxt[g][m];
-        }
-    }
-
-    vk_stamp(d, 2);
-    if (d.stamps != nullptr && threadIdx.x == 0)
-        d.stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 4] = boundary_ticks;
+    const int L = p.length;
     // ---------------------------------- epilogue ----------------------------------------
     // Interior tiles (every row and column of the wave's tile in range) take a branch-free
     // path: wave-uniform row pointers plus one per-lane offset, the epilogue's loads issued
@@ -367,7 +213,6 @@ conv_mfma_kernel(const ConvDev d)
     const int64_t o2b = (int64_t)b * p.out2_bstride;
     const int rows_total = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
     const bool interior = (t0 + wn * TNW + TNW <= L) && ((mt0 + A_REP) * 32 <= rows_total);
-    if ((d.dbg & 1) && acc[0][0][0] != 12345.678f) return;
 
     if (interior) {
         const float* maskb = p.mask ? p.mask + (int64_t)b * L : nullptr;
@@ -594,4 +439,172 @@ conv_mfma_kernel(const ConvDev d)
             }
         }
     }
+}
+
+template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT, bool VEC>
+__global__ void __launch_bounds__(64 * WM * WN, (EPI == VK_EPI_SAMPLE) ? 2 : ((WM == 1 && WN == 4) ? 3 : 4))   // second figure: waves per SIMD the register budget must allow
+conv_mfma_kernel(const ConvDev d)
+{
+    constexpr int NW  = WM * WN;
+    constexpr int TNW = 32 * B_REP;          // time steps per wave
+    constexpr int TN  = TNW * WN;            // time steps per workgroup
+    constexpr int NJ  = TN / 64 + 1;         // 64-column pieces per staged row (halo <= 64)
+    constexpr int NJ4 = (TN + 70 + 255) / 256;   // 64-lane x float4 pieces per staged row (vector staging)
+    constexpr int RPW = CK / NW;             // staged rows per wave per chunk
+    constexpr int GPC = CK / 8;              // weight groups per (chunk, tap)
+    static_assert(CK % NW == 0 && CK % 8 == 0, "chunk must split over waves and k-groups");
+    static_assert(TN % 64 == 0, "time tile must be a multiple of the wave width");
+    constexpr bool PAIR = (EPI == VK_EPI_GATE || EPI == VK_EPI_SAMPLE);
+    static_assert(!PAIR || (A_REP % 2 == 0), "paired epilogues need an even number of row tiles per wave");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const vk_conv_args& p = d.a;
+    const int lane = threadIdx.x & 63;
+    const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm   = w % WM;
+    const int wn   = w / WM;
+    const int half = lane >> 5;
+    const int l31  = lane & 31;
+    const int b    = blockIdx.z;
+    const int t0   = blockIdx.x * TN;
+    const int mt0  = (blockIdx.y * WM + wm) * A_REP;   // first packed 32-row tile of this wave
+    const int L    = p.length;
+    constexpr int STRIDE = TN + 64;          // floats between staged rows (the host checks that tile + halo fits)
+
+    const float* xb = p.x + (int64_t)b * p.x_bstride;
+    vk_stamp(d, 0);
+
+    // ---- staging: global -> registers (issued early) -> LDS (written after the barrier) ----
+    // The column layout of the staged tile is the same for every row and chunk of the tile, so
+    // load offsets and in-range bits are computed once (see the stager structs above).
+    using Stager = typename std::conditional<VEC, VectorStager<RPW, NJ4, NW, CK, ACT>,
+                                                  ScalarStager<RPW, NJ, NW, CK, ACT>>::type;
+    Stager stg;
+    stg.init(d, xb, t0, lane);
+    auto issue_loads = [&](int chunk) { stg.issue(d, chunk, w); };
+    auto store_chunk = [&](int chunk, float* buf) { stg.store(d, chunk, buf, w, lane); };
+    issue_loads(0);          // first: the longest latency of the prologue; weights and bias follow it
+
+    // ---- weight stream: one float4 per lane per 4 k-steps per row tile ----
+    const float4* aptr[A_REP];
+#pragma unroll
+    for (int m = 0; m < A_REP; ++m)
+        aptr[m] = reinterpret_cast<const float4*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
+
+    // Weight fragments are fetched one whole tap (GPC groups) ahead: the loads for tap+1 are
+    // issued when tap starts and first touched when it ends, so a full tap of MFMAs covers
+    // them, and the in-order memory counter gives the chunk's staging loads the same cover.
+    float4 a[GPC][A_REP];
+#pragma unroll
+    for (int g = 0; g < GPC; ++g)
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) a[g][m] = aptr[m][64 * g];
+
+    // Accumulators start at the bias of their row (so no epilogue adds it): register r of this
+    // lane is row (r & 3) + 8 * (r >> 2) + 4 * half of the 32-row tile.
+    f32x16 acc[A_REP][B_REP];
+    {
+        const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
+        const int rows_total_b = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) {
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // packed row
+                int brow = prow;                                                        // bias index
+                if (PAIR) brow = ((m & 1) ? p.hidden : 0) + 32 * ((mt0 + m) >> 1) + (prow & 31);
+                if (EPI == VK_EPI_UPSAMPLE) brow = prow % p.c_out;
+                bv[r] = 0.0f;
+                if (biasb != nullptr) {                      // wave-uniform
+                    const float raw = biasb[prow < rows_total_b ? brow : 0];
+                    bv[r] = prow < rows_total_b ? raw : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = bv[r];
+        }
+    }
+
+    // transposed conv: row tiles of the upper phases read the staged tile one column later
+    int shift = 0;
+    if (EPI == VK_EPI_UPSAMPLE) {
+        const int phase = (mt0 * 32) / p.c_out;
+        shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
+    }
+    const int bcol = half * STRIDE + wn * TNW + l31 + shift + d.col0;
+    
+    unsigned long long boundary_ticks = 0;      // diagnostic: time spent handing over chunks 1..n-1
+    for (int chunk = 0; chunk < d.nchunk; ++chunk) {
+        float* buf = lds + (chunk & 1) * (CK * STRIDE);
+        unsigned long long tb0 = 0;
+        if (d.stamps) tb0 = __builtin_amdgcn_s_memrealtime();
+        if (!(d.dbg & 4) || chunk == 0) store_chunk(chunk, buf);
+        if (!(d.dbg & 8) || chunk == 0) __syncthreads();
+        if (chunk == 0) vk_stamp(d, 1);
+        else if (d.stamps) boundary_ticks += __builtin_amdgcn_s_memrealtime() - tb0;
+        if (chunk + 1 < d.nchunk && !(d.dbg & 4)) issue_loads(chunk + 1);
+        if (d.dbg & 2) continue;
+
+        // k-steps walk channel pairs within a tap, then taps; the B fragments of the next
+        // k-step are read from LDS before the current k-step's MFMAs are issued.  Within a tap
+        // every read is the tap's base address plus a compile-time offset.
+        const float* bt = buf + bcol;
+        float bf[B_REP];
+#pragma unroll
+        for (int n = 0; n < B_REP; ++n) bf[n] = bt[32 * n];
+#pragma unroll 1
+        for (int tap = 0; tap < p.taps; ++tap) {
+            const float* bt_next = (tap + 1 < p.taps) ? bt + p.dilation : buf + bcol;   // chunk end: harmless re-read
+            float4 a_nxt[GPC][A_REP];
+#pragma unroll
+            for (int g = 0; g < GPC; ++g)
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a_nxt[g][m] = aptr[m][64 * (GPC + g)];
+            __builtin_amdgcn_sched_group_barrier(0x020, GPC * A_REP, 0);
+#pragma unroll
+            for (int g = 0; g < GPC; ++g) {
+                float4 a_cur[A_REP];
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a_cur[m] = a[g][m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    constexpr int KSTEPS = 4 * GPC;
+                    const int ks = 4 * g + e;
+                    float bn[B_REP];
+#pragma unroll
+                    for (int n = 0; n < B_REP; ++n)
+                        bn[n] = (ks + 1 < KSTEPS) ? bt[2 * (ks + 1) * STRIDE + 32 * n] : bt_next[32 * n];
+#pragma unroll
+                    for (int m = 0; m < A_REP; ++m) {
+                        const float av = (e == 0) ? a_cur[m].x : (e == 1) ? a_cur[m].y
+                                       : (e == 2) ? a_cur[m].z : a_cur[m].w;
+#pragma unroll
+                        for (int n = 0; n < B_REP; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[n], acc[m][n], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
+                    __builtin_amdgcn_sched_group_barrier(0x100, (B_REP + 1) / 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, A_REP * B_REP, 0);
+                }
+            }
+            bt = bt_next;
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * GPC;
+#pragma unroll
+            for (int g = 0; g < GPC; ++g)
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a[g][m] = a_nxt[g][m];
+        }
+    }
+
+    vk_stamp(d, 2);
+    if (d.stamps != nullptr && threadIdx.x == 0)
+        d.stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 4] = boundary_ticks;
+    if ((d.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    conv_epilogue<A_REP, B_REP, EPI>(d, acc, b, t0, mt0, wn, half, l31);
 }

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -45,6 +46,23 @@ class WeightNormConvParams(nn.Module):
         return packing.fold_weight_norm(self.weight_v.detach(), self.weight_g.detach())
 
 
+_precision = native.PREC_BF16 if os.environ.get("VITS_AMD_PRECISION", "fp32").lower() == "bf16" else native.PREC_F32
+
+
+def set_precision(name: str) -> None:
+    """Matrix-core input precision of every convolution launched afterwards: "fp32" (exact fp32
+    products, the <= 1e-4 parity path) or "bf16" (activations and weights rounded to bf16 at the
+    matrix-core inputs, fp32 accumulation and fp32 tensors in memory)."""
+    global _precision
+    if name not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    _precision = native.PREC_BF16 if name == "bf16" else native.PREC_F32
+
+
+def precision() -> int:
+    return _precision
+
+
 def choose_tile(rows: int) -> int:
     """Tile family for a GEMM with ``rows`` output rows: least row padding, then the
     largest rows-per-workgroup."""
@@ -70,7 +88,11 @@ class PackedConv:
         self.pad = (self.taps - 1) * dilation // 2 if pad is None else pad
         self.tile = choose_tile(w.shape[0]) if tile is None else tile
         ti = native.tile_info(self.tile)
-        self.w = packing.pack_conv_weight(w, ti.ck, ti.rows_per_block, row_order)
+        self.precision = precision()
+        if self.precision == native.PREC_BF16:
+            self.w = packing.pack_conv_weight_bf16(w, ti.ck_bf16, ti.rows_per_block, row_order)
+        else:
+            self.w = packing.pack_conv_weight(w, ti.ck, ti.rows_per_block, row_order)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
@@ -84,7 +106,7 @@ class PlanCache:
         self._plan = None
 
     def get(self, device):
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self._module.parameters())
+        key = (str(device), precision()) + tuple((p.data_ptr(), p._version) for p in self._module.parameters())
         if key != self._key:
             with torch.no_grad():
                 self._plan = self._builder(device)

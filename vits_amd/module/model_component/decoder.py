@@ -43,7 +43,8 @@ class ResBlockPlan:
         # for the two-launch form) and loses at 64 (120 vs 126), so wider blocks stay unfused;
         # VITS_AMD_PAIR_FUSION = "none" / "all" overrides the width limit.
         mode = os.environ.get("VITS_AMD_PAIR_FUSION", "narrow")
-        pi = None if mode == "none" else native.pair_info(rb.channels)
+        from ...engine import precision
+        pi = None if (mode == "none" or precision() != native.PREC_F32) else native.pair_info(rb.channels)
         k = rb.kernel_size
         self.fused = (pi is not None and (rb.channels <= 32 or mode == "all") and k % 2 == 1 and k <= 13
                       and all((k - 1) * d <= 52 for d in rb.dilation))

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvits_amd.so")
 
 TILE_M128, TILE_M64, TILE_M32, TILE_PAIR = 0, 1, 2, 3
+PREC_F32, PREC_BF16 = 0, 1
 (EPI_STORE, EPI_RESID, EPI_RESID_ACC, EPI_RESID_AVG, EPI_GATE, EPI_WN_MID, EPI_WN_LAST,
  EPI_COUPLE_REV, EPI_COUPLE_FWD, EPI_UPSAMPLE, EPI_SAMPLE) = range(11)
 
@@ -22,7 +23,7 @@ _fp = C.c_void_p
 
 class TileInfo(C.Structure):
     _fields_ = [("ck", C.c_int32), ("rows_per_block", C.c_int32),
-                ("time_tile", C.c_int32), ("a_rep", C.c_int32)]
+                ("time_tile", C.c_int32), ("a_rep", C.c_int32), ("ck_bf16", C.c_int32)]
 
 
 class ConvArgs(C.Structure):
@@ -42,6 +43,7 @@ class ConvArgs(C.Structure):
         ("act_in", C.c_int32), ("in_slope", C.c_float),
         ("first", C.c_int32), ("hidden", C.c_int32), ("up_stride", C.c_int32),
         ("navg", C.c_float),
+        ("precision", C.c_int32),
     ]
 
 
@@ -84,7 +86,7 @@ def lib():
                                         C.c_float, C.c_void_p]
         L.vk_pair_query.argtypes = [C.c_int, C.POINTER(TileInfo)]
         L.vk_resblock_pair.argtypes = [C.POINTER(PairArgs), C.c_void_p]
-        if L.vk_abi_version() != 1:
+        if L.vk_abi_version() != 2:
             raise NativeError("libvits_amd.so ABI version mismatch")
         _lib = L
     return _lib
@@ -208,13 +210,24 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     a.tile, a.epilogue = tile, epilogue
     a.act_in, a.in_slope = int(act_in), in_slope
     a.first, a.hidden, a.up_stride, a.navg = int(first), hidden, up_stride, navg
+    # the packed weight format names the matrix-core input precision
+    assert w_packed.dtype in (torch.float32, torch.bfloat16)
+    precision = PREC_BF16 if w_packed.dtype == torch.bfloat16 else PREC_F32
+    a.precision = precision
     rows = c_out * up_stride if epilogue == EPI_UPSAMPLE else c_out
     flops = 2.0 * x.shape[0] * x.shape[2] * rows * c_in * taps
-    family = f"conv_mfma[{_TILE_NAMES[tile]},{_EPI_NAMES[epilogue]},act={int(act_in)}]"
+    family = (f"conv_{'bf16' if precision == PREC_BF16 else 'mfma'}"
+              f"[{_TILE_NAMES[tile]},{_EPI_NAMES[epilogue]},act={int(act_in)}]")
     L = lib()
     sp = stream_ptr(x.device)
     detail = f"B{x.shape[0]} L{x.shape[2]} {c_in}->{rows} k{taps} d{dilation}"
-    check(_timed(family, flops, 0.0, x.device, lambda: L.vk_conv1d(C.byref(a), sp), detail), "vk_conv1d")
+    # algorithmic bytes: every activation view the launch reads or writes, once
+    nbytes = 4.0 * (x.shape[0] * c_in * x.shape[2] + out.numel())
+    if res is not None and res.data_ptr() != x.data_ptr():
+        nbytes += 4.0 * res.numel()
+    if out2 is not None and epilogue in (EPI_RESID_ACC, EPI_RESID_AVG, EPI_WN_MID, EPI_WN_LAST, EPI_SAMPLE):
+        nbytes += 4.0 * out2.numel()
+    check(_timed(family, flops, nbytes, x.device, lambda: L.vk_conv1d(C.byref(a), sp), detail), "vk_conv1d")
 
 
 def resblock_pair(x, w1, bias1, w2, bias2, out, *, taps, dilation, epilogue, slope, acc=None, navg=1.0):

@@ -44,6 +44,28 @@ def pack_conv_weight(w: torch.Tensor, ck: int, rows_per_block: int, row_order=No
     return torch.cat([flat, torch.zeros(4 * 256, dtype=torch.float32, device=w.device)])
 
 
+def pack_conv_weight_bf16(w: torch.Tensor, ck: int, rows_per_block: int, row_order=None) -> torch.Tensor:
+    """w [rows, c_in, taps] -> flat bf16 tensor in the fragment order of the bf16-input kernels
+    (csrc/conv_bf16.hpp):
+
+        packed[mt][chunk][tap][kstep][lane][i] = bf16(W[row(32*mt + (lane & 31)), chunk*CK + 16*kstep + 8*(lane >> 5) + i, tap])
+
+    one 16-byte fragment per lane per v_mfma_f32_32x32x16_bf16; rounding is to nearest even."""
+    w = w.detach().to(torch.float32)
+    if row_order is not None:
+        w = w[row_order]
+    rows, cin, taps = w.shape
+    rpad = -(-rows // rows_per_block) * rows_per_block
+    cpad = -(-cin // ck) * ck
+    wp = torch.zeros(rpad, cpad, taps, dtype=torch.float32, device=w.device)
+    wp[:rows, :cin] = w
+    mt, nch, ks = rpad // 32, cpad // ck, ck // 16
+    # [mt, r, chunk, kstep, h, i, tap] -> [mt, chunk, tap, kstep, h, r, i]
+    wp = wp.view(mt, 32, nch, ks, 2, 8, taps).permute(0, 2, 6, 3, 4, 1, 5).contiguous()
+    flat = wp.view(-1).to(torch.bfloat16)
+    return torch.cat([flat, torch.zeros(8 * 512, dtype=torch.bfloat16, device=w.device)])
+
+
 def pair_row_order(hidden: int) -> torch.Tensor:
     """Row order that interleaves 32-row tiles of the two halves of a 2*hidden-row output:
     [a0, b0, a1, b1, ...] with a_q = rows 32q.., b_q = rows hidden + 32q.."""
