@@ -167,3 +167,26 @@ def voice_conversion(spec, lengths, src_ids, tgt_ids, sd, eps):
     z_p = flow(z, mask, g_src, sd, reverse=False)
     z_hat = flow(z_p, mask, g_tgt, sd, reverse=True)
     return decoder(z_hat * mask, g_tgt, sd)
+
+
+def power_spectrogram(wav, filter_length: int = 1024, hop_length: int = 256, win_length: int = 1024):
+    """Front end of voice conversion, /root/reference/vits_voice_converter.py:82-96: reflect
+    padding by (filter_length - hop_length) / 2, un-centred frames every hop_length samples,
+    periodic Hann window, one-sided DFT, squared magnitude.  Plain float64 numpy DFT per
+    frame.  torchaudio (which the reference calls) is not installed, so this restates its
+    documented ``spectrogram(power=2, normalized=False, center=False, pad=0)``: parity with
+    torchaudio itself is unpinned."""
+    import numpy as np
+    x = wav.detach().cpu().to(torch.float64).numpy()
+    lead = x.shape[:-1]
+    x = x.reshape(-1, x.shape[-1])
+    pad = (filter_length - hop_length) // 2
+    x = np.pad(x, ((0, 0), (pad, pad)), mode="reflect")
+    n = np.arange(win_length)
+    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)          # torch.hann_window: periodic
+    frames = 1 + (x.shape[1] - filter_length) // hop_length
+    out = np.empty((x.shape[0], filter_length // 2 + 1, frames))
+    for f in range(frames):
+        seg = x[:, f * hop_length:f * hop_length + filter_length] * window
+        out[:, :, f] = np.abs(np.fft.rfft(seg, n=filter_length, axis=1)) ** 2
+    return torch.from_numpy(out.reshape(*lead, out.shape[1], frames)).to(torch.float32)

@@ -2,7 +2,8 @@
 """Times the BASELINE.json configurations other than the headline one (needs a GPU):
   1  text_to_speech, one ~4 s sentence: CPU oracle path vs the drop-in generator on the GPU
   2  decoder only, B=1, T=862 and T=258 (latency)
-  4  voice conversion (posterior encoder -> flow fwd -> flow rev -> decoder), B=64, T=862, fp32
+  4  voice conversion (posterior encoder -> flow fwd -> flow rev -> decoder), B=64, T=862, fp32 and
+     with bf16 matrix-core inputs
 Prints one line per case.  (Config 3 is bench.py's default, config 5 is bench.py --workload corpus.)"""
 import sys
 import time
@@ -62,12 +63,22 @@ for T in (862, 258):
     dt, _ = timed(lambda: graphed(z, gd), 50)
     print(f"config 2  same, replayed as one HIP graph:  {dt*1e3:7.2f} ms = {T*256/22050/dt:7.0f} x RT")
 
-# ---- config 4 (fp32; the bf16 variant is not built)
+# ---- config 4
 B, T = 64, 862
 spec = synth.power_spectrogram(999, "cfg4.spec", B, T).to(dev)
 lens4 = torch.full((B,), T, device=dev)
 src = synth.speaker_ids(999, "cfg4.src", B).to(dev); tgt = synth.speaker_ids(999, "cfg4.tgt", B).to(dev)
 eps = synth.latent(999, "cfg4.eps", B, T).to(dev)
-dt, wav = timed(lambda: gen.voice_conversion(spec, lens4, src, tgt, noise=eps), 3)
-print(f"config 4  voice conversion B={B} T={T} fp32: {dt*1e3:8.1f} ms = {B*T*256/22050/dt:7.0f} x RT  (566.9 GFLOP/utt -> "
-      f"{B*566.89e9/dt/1e12:.1f} TFLOP/s)")
+from vits_amd import engine
+wav32 = None
+for prec in ("fp32", "bf16"):
+    engine.set_precision(prec)
+    dt, wav = timed(lambda: gen.voice_conversion(spec, lens4, src, tgt, noise=eps), 3)
+    extra = ""
+    if prec == "fp32":
+        wav32 = wav
+    else:
+        extra = f"  max-abs vs fp32 {(wav - wav32).abs().max().item():.2e} (|wav|max {wav32.abs().max().item():.2f})"
+    print(f"config 4  voice conversion B={B} T={T} {prec}: {dt*1e3:8.1f} ms = {B*T*256/22050/dt:7.0f} x RT  "
+          f"(566.9 GFLOP/utt -> {B*566.89e9/dt/1e12:.1f} TFLOP/s){extra}")
+engine.set_precision("fp32")
