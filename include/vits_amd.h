@@ -127,7 +127,7 @@ int vk_conv1d(const vk_conv_args* a, void* stream);
  *   out = conv2(lrelu(h, slope)) + x        taps k, dilation 1, padding (k-1)/2
  * (decoder.py:49-58), optionally folded into the sum over a stage's resblocks
  * (decoder.py:119-125) through VK_EPI_RESID_ACC / VK_EPI_RESID_AVG.  The intermediate h
- * stays in LDS.  Built for the channel widths vk_pair_query accepts (32 and 64); other
+ * stays in LDS.  Built for the channel widths vk_pair_query accepts; other
  * widths use two vk_conv1d launches.  `out` must not overlap `x` (neighbouring
  * workgroups read halo columns of x); `acc` may be the same view as `out`.            */
 typedef struct {
@@ -140,11 +140,13 @@ typedef struct {
     int32_t taps, dilation;                     /* taps odd, <= 13; (taps-1)*dilation <= 52 */
     int32_t epilogue;                           /* VK_EPI_RESID, VK_EPI_RESID_ACC, VK_EPI_RESID_AVG */
     float   slope, navg;
+    int32_t precision;                          /* VK_PREC_F32 (32/64 channels) or VK_PREC_BF16 (32/64/128) */
 } vk_pair_args;
 
-/* Packing geometry of the fused kernel for this channel width (VK_E_UNSUPPORTED if none);
- * time_tile is the number of output columns a workgroup keeps.                        */
-int vk_pair_query(int channels, vk_tile_info* info);
+/* Packing geometry of the fused kernel for this channel width and precision
+ * (VK_E_UNSUPPORTED if none): weights are packed with `ck` (fp32) or `ck_bf16` (bf16) and
+ * `rows_per_block`; time_tile is the number of output columns a workgroup keeps.       */
+int vk_pair_query(int channels, int precision, vk_tile_info* info);
 int vk_resblock_pair(const vk_pair_args* a, void* stream);
 
 /* out[b, o] = bias[o] + sum_i W[o, i] * g[b, i]   (speaker-conditioning 1x1 convs on

@@ -222,7 +222,7 @@ def test_fused_pair_rejects_bad_arguments():
     with pytest.raises(native.NativeError):      # halo too long
         native.resblock_pair(x, wp, b, wp, b, torch.empty_like(x), taps=3, dilation=30,
                              epilogue=native.EPI_RESID, slope=0.1)
-    assert native.pair_info(128) is None
+    assert native.pair_info(128) is None and native.pair_info(256, native.PREC_BF16) is None
     x128 = torch.zeros(1, 128, 64, device=DEV)
     with pytest.raises(native.NativeError):      # width without a fused kernel
         native.resblock_pair(x128, wp, b, wp, b, torch.empty_like(x128), taps=3, dilation=1,
@@ -299,3 +299,50 @@ def test_bf16_gate_epilogue():
                   taps=5, dilation=1, pad=2, tile=native.TILE_PAIR, epilogue=native.EPI_GATE, bias=cond.to(DEV),
                   bias_bstride=2 * H, hidden=H)
     _close(acts, ref, "bf16 gate")
+
+
+@pytest.mark.parametrize("ch,k,dil,B,L", [
+    (32, 3, 1, 2, 1),
+    (32, 11, 5, 2, 37),
+    (32, 7, 3, 2, 501),          # one column into the second workgroup
+    (64, 11, 5, 2, 463),
+    (64, 3, 3, 3, 1200),
+    (128, 7, 1, 1, 244),         # exactly one 128-channel workgroup
+    (128, 11, 5, 2, 777),
+])
+def test_bf16_fused_resblock_pair(ch, k, dil, B, L):
+    x = _rand(B, ch, L, seed=91)
+    w1 = _rand(ch, ch, k, seed=92) / (ch * k) ** 0.5
+    w2 = _rand(ch, ch, k, seed=93) / (ch * k) ** 0.5
+    b1, b2 = _rand(ch, seed=94), _rand(ch, seed=95)
+    h = F.conv1d(_r16(F.leaky_relu(x, 0.1)), _r16(w1), b1, padding=(k - 1) * dil // 2, dilation=dil)
+    ref = F.conv1d(_r16(F.leaky_relu(h, 0.1)), _r16(w2), b2, padding=(k - 1) // 2) + x
+    pi = native.pair_info(ch, native.PREC_BF16)
+    assert pi is not None
+    p1 = packing.pack_conv_weight_bf16(w1, pi.ck_bf16, pi.rows_per_block).to(DEV)
+    p2 = packing.pack_conv_weight_bf16(w2, pi.ck_bf16, pi.rows_per_block).to(DEV)
+    xd = x.to(DEV)
+    out = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.resblock_pair(xd, p1, b1.to(DEV), p2, b2.to(DEV), out, taps=k, dilation=dil,
+                         epilogue=native.EPI_RESID, slope=0.1)
+    # h is rounded to bf16 between the convolutions: a value on a rounding boundary may fall
+    # either way depending on the summation order, so allow one bf16 step of one h element
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+    assert (got - ref).abs().mean().item() <= 2e-5
+    accb = _rand(B, ch, L, seed=96)
+    acc = accb.to(DEV).clone()
+    native.resblock_pair(xd, p1, b1.to(DEV), p2, b2.to(DEV), acc, taps=k, dilation=dil,
+                         epilogue=native.EPI_RESID_AVG, slope=0.1, acc=acc, navg=3.0)
+    assert ((acc.cpu() - (accb + ref) / 3.0).abs().max().item()) <= 1e-3
+    # and bit-for-bit what two separate bf16 convolution launches produce
+    tile = choose_tile(ch)
+    tmp = torch.empty_like(out)
+    two = torch.empty_like(out)
+    native.conv1d(xd, _pack16(w1, tile), tmp, c_in=ch, c_out=ch, taps=k, dilation=dil, pad=(k - 1) * dil // 2,
+                  tile=tile, epilogue=native.EPI_STORE, bias=b1.to(DEV), act_in=True, in_slope=0.1)
+    native.conv1d(tmp, _pack16(w2, tile), two, c_in=ch, c_out=ch, taps=k, dilation=1, pad=(k - 1) // 2,
+                  tile=tile, epilogue=native.EPI_RESID, bias=b2.to(DEV), res=xd, act_in=True, in_slope=0.1)
+    assert (two - out).abs().max().item() <= 2e-3

@@ -17,6 +17,119 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Staging of one K-chunk for the bf16 kernels.  Work unit = (group of 8 channels, 64-column
+// piece); unit id = w + NW * i for wave w.  A lane owns one column of its unit: 8 coalesced
+// 4-byte loads (one per channel), activation, rounding, one 16-byte LDS store.
+template <int NW, int NJ, int CK, int PITCH, bool ACT>
+struct Bf16Stager {
+    static constexpr int CG = CK / 8;
+    static constexpr int NP = NJ * CG;
+    static constexpr int NI = (NP + NW - 1) / NW;
+    int  u_voff[NI];        // clamped byte offset of this lane's column within a row of x
+    int  u_lds[NI];         // byte offset of this lane's 16-byte slot within a staging buffer
+    int  u_cg[NI];          // channel group (wave-uniform)
+    bool u_in[NI];          // this lane's column lies inside [0, L)
+    bool u_on[NI];          // wave-uniform: the unit exists and its piece overlaps the staged width
+    float st[NI][8];
+    __amdgpu_buffer_rsrc_t rx;
+
+    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane, int w)
+    {
+        const int L = d.a.length;
+        rx = vk_rsrc(xb, d.x_bytes);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int pid = w + NW * i;
+            const int cg = pid / NJ, piece = pid - cg * NJ;
+            const int col = piece * 64 + lane;
+            const int t = t0 - d.a.pad + (col < d.xw ? col : d.xw - 1);   // lanes past the staged width re-read its last column
+            u_cg[i] = cg;
+            u_on[i] = (pid < NP) && (piece * 64 < d.xw);
+            u_voff[i] = 4 * (t < 0 ? 0 : (t >= L ? L - 1 : t));
+            u_in[i] = (t >= 0) && (t < L);
+            u_lds[i] = col * PITCH + cg * 16;
+        }
+    }
+    __device__ __forceinline__ void issue(const ConvDev& d, int chunk)
+    {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (u_on[i]) {                                           // wave-uniform
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const int c = chunk * CK + u_cg[i] * 8 + c8;
+                    const int soff = (int)((c < d.a.c_in ? c : 0) * d.a.x_cstride * 4);
+                    st[i][c8] = vk_bld(rx, u_voff[i], soff);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const ConvDev& d, int chunk, char* buf)
+    {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (u_on[i]) {
+                bf16x8 o;
+#pragma unroll
+                for (int c8 = 0; c8 < 8; c8 += 2) {
+                    const int c = chunk * CK + u_cg[i] * 8 + c8;
+                    float v0 = (u_in[i] && c < d.a.c_in) ? st[i][c8] : 0.0f;
+                    float v1 = (u_in[i] && c + 1 < d.a.c_in) ? st[i][c8 + 1] : 0.0f;
+                    if (ACT) { v0 = vk_lrelu(v0, d.a.in_slope); v1 = vk_lrelu(v1, d.a.in_slope); }
+                    const f32x2 pr = {v0, v1};
+                    const bf16x2 q = __builtin_convertvector(pr, bf16x2);
+                    o[c8] = q[0]; o[c8 + 1] = q[1];
+                }
+                *reinterpret_cast<bf16x8*>(buf + u_lds[i]) = o;
+            }
+        }
+    }
+};
+
+// The k-loop over one resident chunk (KS matrix instructions per tap): weights fetched one tap
+// ahead, B fragments of the next k-step read before the current k-step's MFMAs are issued.
+// `base` is this lane's fragment address for tap 0 / k-step 0 / column tile 0.
+template <int A_REP, int B_REP, int KS, int PITCH>
+__device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&a)[KS][A_REP],
+                                          const bf16x8* (&aptr)[A_REP], const char* base, int taps, int tap_step)
+{
+    const char* bt = base;
+    bf16x8 bf[B_REP];
+#pragma unroll
+    for (int n = 0; n < B_REP; ++n) bf[n] = *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH);
+#pragma unroll 1
+    for (int tap = 0; tap < taps; ++tap) {
+        const char* bt_next = (tap + 1 < taps) ? bt + tap_step : base;     // chunk end: harmless re-read
+        bf16x8 a_nxt[KS][A_REP];
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = aptr[m][64 * (KS + k)];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            bf16x8 bn[B_REP];
+#pragma unroll
+            for (int n = 0; n < B_REP; ++n)
+                bn[n] = (k + 1 < KS) ? *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH + (k + 1) * 32)
+                                     : *reinterpret_cast<const bf16x8*>(bt_next + n * 32 * PITCH);
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k][m], bf[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
+        }
+        bt = bt_next;
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * KS;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m) a[k][m] = a_nxt[k][m];
+    }
+}
+
 template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 conv_bf16_kernel(const ConvDev d)
@@ -25,9 +138,6 @@ conv_bf16_kernel(const ConvDev d)
     constexpr int TNW = 32 * B_REP;
     constexpr int TN  = TNW * WN;
     constexpr int NJ  = TN / 64 + 1;            // 64-column pieces per staged tile (halo <= 64)
-    constexpr int CG  = CK / 8;                 // groups of 8 channels per chunk
-    constexpr int NP  = NJ * CG;                // (piece, group) staging units per chunk
-    constexpr int NI  = (NP + NW - 1) / NW;     // units per wave
     constexpr int KS  = CK / 16;                // matrix instructions per tap per chunk
     constexpr int PITCH = CK * 2 + 16;          // bytes between staged columns (odd multiple of 16: conflict-free)
     constexpr int BUF = (TN + 64) * PITCH;      // bytes per staging buffer
@@ -51,60 +161,9 @@ conv_bf16_kernel(const ConvDev d)
     const int L    = p.length;
 
     const float* xb = p.x + (int64_t)b * p.x_bstride;
-    const __amdgpu_buffer_rsrc_t rx = vk_rsrc(xb, d.x_bytes);
-
-    // ---- staging units of this wave: unit id = w + NW * i -> (channel group, 64-column piece) ----
-    int  u_voff[NI];        // clamped byte offset of this lane's column within a row of x
-    int  u_lds[NI];         // byte offset of this lane's 16-byte slot within a staging buffer
-    int  u_cg[NI];          // channel group (wave-uniform)
-    bool u_in[NI];          // this lane's column lies inside [0, L)
-    bool u_on[NI];          // wave-uniform: the unit exists and its piece overlaps the staged width
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int pid = w + NW * i;
-        const int cg = pid / NJ, piece = pid - cg * NJ;
-        const int col = piece * 64 + lane;
-        const int t = t0 - p.pad + (col < d.xw ? col : d.xw - 1);     // lanes past the staged width re-read its last column
-        u_cg[i] = cg;
-        u_on[i] = (pid < NP) && (piece * 64 < d.xw);
-        u_voff[i] = 4 * (t < 0 ? 0 : (t >= L ? L - 1 : t));
-        u_in[i] = (t >= 0) && (t < L);
-        u_lds[i] = col * PITCH + cg * 16;
-    }
-    float st[NI][8];
-    auto issue_loads = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (u_on[i]) {                                           // wave-uniform
-#pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    const int c = chunk * CK + u_cg[i] * 8 + c8;
-                    const int soff = (int)((c < p.c_in ? c : 0) * p.x_cstride * 4);
-                    st[i][c8] = vk_bld(rx, u_voff[i], soff);
-                }
-            }
-        }
-    };
-    auto store_chunk = [&](int chunk, char* buf) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (u_on[i]) {
-                bf16x8 o;
-#pragma unroll
-                for (int c8 = 0; c8 < 8; c8 += 2) {
-                    const int c = chunk * CK + u_cg[i] * 8 + c8;
-                    float v0 = (u_in[i] && c < p.c_in) ? st[i][c8] : 0.0f;
-                    float v1 = (u_in[i] && c + 1 < p.c_in) ? st[i][c8 + 1] : 0.0f;
-                    if (ACT) { v0 = vk_lrelu(v0, p.in_slope); v1 = vk_lrelu(v1, p.in_slope); }
-                    const f32x2 pr = {v0, v1};
-                    const bf16x2 q = __builtin_convertvector(pr, bf16x2);
-                    o[c8] = q[0]; o[c8 + 1] = q[1];
-                }
-                *reinterpret_cast<bf16x8*>(buf + u_lds[i]) = o;
-            }
-        }
-    };
-    issue_loads(0);
+    Bf16Stager<NW, NJ, CK, PITCH, ACT> stg;
+    stg.init(d, xb, t0, lane, w);
+    stg.issue(d, 0);
 
     // ---- weight stream: one 16-byte fragment per lane per matrix instruction ----
     const bf16x8* aptr[A_REP];
@@ -154,45 +213,10 @@ conv_bf16_kernel(const ConvDev d)
 
     for (int chunk = 0; chunk < d.nchunk; ++chunk) {
         char* buf = lds8 + (chunk & 1) * BUF;
-        store_chunk(chunk, buf);
+        stg.store(d, chunk, buf);
         __syncthreads();
-        if (chunk + 1 < d.nchunk) issue_loads(chunk + 1);
-
-        const char* bt = buf + bcol;
-        bf16x8 bf[B_REP];
-#pragma unroll
-        for (int n = 0; n < B_REP; ++n) bf[n] = *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH);
-#pragma unroll 1
-        for (int tap = 0; tap < p.taps; ++tap) {
-            const char* bt_next = (tap + 1 < p.taps) ? bt + tap_step : buf + bcol;
-            bf16x8 a_nxt[KS][A_REP];
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = aptr[m][64 * (KS + k)];
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                bf16x8 bn[B_REP];
-#pragma unroll
-                for (int n = 0; n < B_REP; ++n)
-                    bn[n] = (k + 1 < KS) ? *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH + (k + 1) * 32)
-                                         : *reinterpret_cast<const bf16x8*>(bt_next + n * 32 * PITCH);
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m)
-#pragma unroll
-                    for (int n = 0; n < B_REP; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k][m], bf[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
-            }
-            bt = bt_next;
-#pragma unroll
-            for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * KS;
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m) a[k][m] = a_nxt[k][m];
-        }
+        if (chunk + 1 < d.nchunk) stg.issue(d, chunk + 1);
+        bf16_taps<A_REP, B_REP, KS, PITCH>(acc, a, aptr, buf + bcol, p.taps, tap_step);
     }
 
     conv_epilogue<A_REP, B_REP, EPI>(d, acc, b, t0, mt0, wn, half, l31);

@@ -23,6 +23,55 @@ struct PairDev {
 
 constexpr int VK_PAIR_OVERLAP = 12;
 
+// out = acc + x (+ running sum) for the first TNO columns of the workgroup's window.
+template <int B_REP, int EPI, int TNO>
+__device__ __forceinline__ void pair_epilogue(const ConvDev& d, f32x16 (&acc)[B_REP], int b, int t0, int wm, int wn,
+                                              int half, int l31)
+{
+    constexpr int TNW = 32 * B_REP;
+    const vk_conv_args& p = d.a;
+    const int L = p.length;
+    // ---- epilogue: out = acc + x (+ running sum), valid columns only ----
+    const int64_t ob  = (int64_t)b * p.out_bstride;
+    const int64_t rb  = (int64_t)b * p.res_bstride;
+    const int64_t o2b = (int64_t)b * p.out2_bstride;
+    const __amdgpu_buffer_rsrc_t r_out  = vk_rsrc(p.out + ob, d.out_bytes);
+    const __amdgpu_buffer_rsrc_t r_res  = vk_rsrc(p.res + rb, d.res_bytes);
+    const __amdgpu_buffer_rsrc_t r_out2 = vk_rsrc(p.out2 ? p.out2 + o2b : p.out + ob, p.out2 ? d.out2_bytes : 0u);
+    constexpr bool NEED_ACC = (EPI == VK_EPI_RESID_ACC || EPI == VK_EPI_RESID_AVG);
+    const int cw = wn * TNW + l31;                      // this lane's column for n = 0
+    const int tw = t0 + cw;
+    const int vo  = 4 * (4 * half * (int)p.out_cstride + tw);
+    const int vr  = 4 * (4 * half * (int)p.res_cstride + tw);
+    const int vo2 = 4 * (4 * half * (int)p.out2_cstride + tw);
+    const int R0 = wm * 32;
+#pragma unroll
+    for (int n = 0; n < B_REP; ++n) {
+        const bool ok = (cw + 32 * n < TNO) && (tw + 32 * n < L);
+        // loads are unconditional: past the view's end the buffer returns zero, and a column
+        // that is not stored may read a neighbouring row
+        float rv[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = R0 + (r & 3) + 8 * (r >> 2);
+            rv[r] = vk_bld(r_res, vr + 128 * n, rr * (int)p.res_cstride * 4);
+            sv[r] = 0.0f;
+            if constexpr (NEED_ACC) sv[r] = vk_bld(r_out2, vo2 + 128 * n, rr * (int)p.out2_cstride * 4);
+        }
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = R0 + (r & 3) + 8 * (r >> 2);
+                const float v = acc[n][r];
+                const int so = rr * (int)p.out_cstride * 4;
+                if constexpr (EPI == VK_EPI_RESID)          vk_bst(v + rv[r], r_out, vo + 128 * n, so);
+                else if constexpr (EPI == VK_EPI_RESID_ACC) vk_bst(sv[r] + (v + rv[r]), r_out, vo + 128 * n, so);
+                else                                        vk_bst((sv[r] + (v + rv[r])) / p.navg, r_out, vo + 128 * n, so);
+            }
+        }
+    }
+}
+
 template <int B_REP, int WM, int WN, int CK, int EPI, bool VEC>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 resblock_pair_kernel(const PairDev q)
@@ -168,45 +217,7 @@ resblock_pair_kernel(const PairDev q)
     for (int chunk = 0; chunk < NCH; ++chunk)
         run_chunk(lds + chunk * (CK * STRIDE) + bcol2, p.taps, 1);
 
-    // ---- epilogue: out = acc + x (+ running sum), valid columns only ----
-    const int64_t ob  = (int64_t)b * p.out_bstride;
-    const int64_t rb  = (int64_t)b * p.res_bstride;
-    const int64_t o2b = (int64_t)b * p.out2_bstride;
-    const __amdgpu_buffer_rsrc_t r_out  = vk_rsrc(p.out + ob, d.out_bytes);
-    const __amdgpu_buffer_rsrc_t r_res  = vk_rsrc(p.res + rb, d.res_bytes);
-    const __amdgpu_buffer_rsrc_t r_out2 = vk_rsrc(p.out2 ? p.out2 + o2b : p.out + ob, p.out2 ? d.out2_bytes : 0u);
-    constexpr bool NEED_ACC = (EPI == VK_EPI_RESID_ACC || EPI == VK_EPI_RESID_AVG);
-    const int cw = wn * TNW + l31;                      // this lane's column for n = 0
-    const int tw = t0 + cw;
-    const int vo  = 4 * (4 * half * (int)p.out_cstride + tw);
-    const int vr  = 4 * (4 * half * (int)p.res_cstride + tw);
-    const int vo2 = 4 * (4 * half * (int)p.out2_cstride + tw);
-    const int R0 = wm * 32;
-#pragma unroll
-    for (int n = 0; n < B_REP; ++n) {
-        const bool ok = (cw + 32 * n < TNO) && (tw + 32 * n < L);
-        // loads are unconditional: past the view's end the buffer returns zero, and a column
-        // that is not stored may read a neighbouring row
-        float rv[16], sv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = R0 + (r & 3) + 8 * (r >> 2);
-            rv[r] = vk_bld(r_res, vr + 128 * n, rr * (int)p.res_cstride * 4);
-            sv[r] = 0.0f;
-            if constexpr (NEED_ACC) sv[r] = vk_bld(r_out2, vo2 + 128 * n, rr * (int)p.out2_cstride * 4);
-        }
-        if (ok) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = R0 + (r & 3) + 8 * (r >> 2);
-                const float v = acc[n][r];
-                const int so = rr * (int)p.out_cstride * 4;
-                if constexpr (EPI == VK_EPI_RESID)          vk_bst(v + rv[r], r_out, vo + 128 * n, so);
-                else if constexpr (EPI == VK_EPI_RESID_ACC) vk_bst(sv[r] + (v + rv[r]), r_out, vo + 128 * n, so);
-                else                                        vk_bst((sv[r] + (v + rv[r])) / p.navg, r_out, vo + 128 * n, so);
-            }
-        }
-    }
+    pair_epilogue<B_REP, EPI, TNO>(d, acc, b, t0, wm, wn, half, l31);
 }
 
 struct PairGeom { int b_rep, wm, wn, ck; };

@@ -38,21 +38,27 @@ def get_padding(kernel_size, dilation=1):
 class ResBlockPlan:
     def __init__(self, rb: "ResNetBlock", device):
         self.pairs = []
-        # The narrowest resblocks run each (dilated conv, plain conv, residual) pair as one
-        # launch.  Measured on the MI355X the fused kernel wins at 32 channels (118 vs 96 TFLOP/s
-        # for the two-launch form) and loses at 64 (120 vs 126), so wider blocks stay unfused;
-        # VITS_AMD_PAIR_FUSION = "none" / "all" overrides the width limit.
-        mode = os.environ.get("VITS_AMD_PAIR_FUSION", "narrow")
+        # Resblocks run each (dilated conv, plain conv, residual) pair as one launch where that
+        # is faster.  fp32: measured on the MI355X the fused kernel wins at 32 channels (118 vs
+        # 96 TFLOP/s for the two-launch form) and loses at 64 (120 vs 126).  bf16 matrix inputs:
+        # the convolutions are HBM-bound, so every width with a fused kernel (32/64/128) uses it.
+        # VITS_AMD_PAIR_FUSION = "none" / "all" overrides the choice.
         from ...engine import precision
-        pi = None if (mode == "none" or precision() != native.PREC_F32) else native.pair_info(rb.channels)
+        mode = os.environ.get("VITS_AMD_PAIR_FUSION", "auto")
+        prec = precision()
+        pi = None if mode == "none" else native.pair_info(rb.channels, prec)
         k = rb.kernel_size
-        self.fused = (pi is not None and (rb.channels <= 32 or mode == "all") and k % 2 == 1 and k <= 13
+        wide_ok = prec == native.PREC_BF16 or rb.channels <= 32 or mode == "all"
+        self.fused = (pi is not None and wide_ok and k % 2 == 1 and k <= 13
                       and all((k - 1) * d <= 52 for d in rb.dilation))
         for j, d in enumerate(rb.dilation):
             c1, c2 = rb.convs1[j], rb.convs2[j]
             if self.fused:
                 def pk(c):
-                    return packing.pack_conv_weight(c.effective_weight().to(device), pi.ck, pi.rows_per_block)
+                    w = c.effective_weight().to(device)
+                    if prec == native.PREC_BF16:
+                        return packing.pack_conv_weight_bf16(w, pi.ck_bf16, pi.rows_per_block)
+                    return packing.pack_conv_weight(w, pi.ck, pi.rows_per_block)
 
                 def bs(c):
                     return c.bias.detach().to(device=device, dtype=torch.float32).contiguous()

@@ -56,7 +56,7 @@ class PairArgs(C.Structure):
         ("acc", _fp), ("acc_bstride", C.c_int64), ("acc_cstride", C.c_int64),
         ("batch", C.c_int32), ("channels", C.c_int32), ("length", C.c_int32),
         ("taps", C.c_int32), ("dilation", C.c_int32), ("epilogue", C.c_int32),
-        ("slope", C.c_float), ("navg", C.c_float),
+        ("slope", C.c_float), ("navg", C.c_float), ("precision", C.c_int32),
     ]
 
 
@@ -84,7 +84,7 @@ def lib():
         L.vk_speaker_linear.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.vk_post_conv_tanh.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_void_p]
-        L.vk_pair_query.argtypes = [C.c_int, C.POINTER(TileInfo)]
+        L.vk_pair_query.argtypes = [C.c_int, C.c_int, C.POINTER(TileInfo)]
         L.vk_resblock_pair.argtypes = [C.POINTER(PairArgs), C.c_void_p]
         if L.vk_abi_version() != 2:
             raise NativeError("libvits_amd.so ABI version mismatch")
@@ -111,13 +111,14 @@ def tile_info(tile: int) -> TileInfo:
 _pair_cache = {}
 
 
-def pair_info(channels: int):
-    """Packing geometry of the fused resblock-pair kernel for this width, or None if the
-    width has no fused kernel."""
-    if channels not in _pair_cache:
+def pair_info(channels: int, precision: int = 0):
+    """Packing geometry of the fused resblock-pair kernel for this width and precision, or
+    None if there is no such kernel."""
+    key = (channels, precision)
+    if key not in _pair_cache:
         ti = TileInfo()
-        _pair_cache[channels] = ti if lib().vk_pair_query(channels, C.byref(ti)) == 0 else None
-    return _pair_cache[channels]
+        _pair_cache[key] = ti if lib().vk_pair_query(channels, precision, C.byref(ti)) == 0 else None
+    return _pair_cache[key]
 
 
 def stream_ptr(device) -> int:
@@ -244,12 +245,15 @@ def resblock_pair(x, w1, bias1, w2, bias2, out, *, taps, dilation, epilogue, slo
     a.batch, a.channels, a.length = x.shape
     a.taps, a.dilation, a.epilogue = taps, dilation, epilogue
     a.slope, a.navg = slope, navg
+    assert w1.dtype == w2.dtype and w1.dtype in (torch.float32, torch.bfloat16)
+    a.precision = PREC_BF16 if w1.dtype == torch.bfloat16 else PREC_F32
     ch = x.shape[1]
     flops = 2.0 * x.shape[0] * x.shape[2] * ch * ch * taps * 2
-    family = f"resblock_pair[c{ch},{_EPI_NAMES[epilogue]}]"
+    family = f"resblock_pair{'_bf16' if a.precision == PREC_BF16 else ''}[c{ch},{_EPI_NAMES[epilogue]}]"
     L, sp = lib(), stream_ptr(x.device)
     detail = f"B{x.shape[0]} L{x.shape[2]} c{ch} k{taps} d{dilation}"
-    check(_timed(family, flops, 0.0, x.device, lambda: L.vk_resblock_pair(C.byref(a), sp), detail),
+    nbytes = 4.0 * (x.numel() + out.numel() + (acc.numel() if acc is not None else 0))
+    check(_timed(family, flops, nbytes, x.device, lambda: L.vk_resblock_pair(C.byref(a), sp), detail),
           "vk_resblock_pair")
 
 
