@@ -46,6 +46,7 @@ typedef struct {
     int32_t time_tile;     /* output columns (time steps) handled by one workgroup    */
     int32_t a_rep;         /* consecutive 32-row tiles owned by one wavefront         */
     int32_t ck_bf16;       /* K-chunk of the bf16-input kernels (VK_PREC_BF16)         */
+    int32_t ck_split;      /* K-chunk of the sliced-fp32 kernels (VK_PREC_F32_SPLIT)   */
 } vk_tile_info;
 
 /* Matrix-core input precision (vk_conv_args.precision).  Activations, bias, residuals and
@@ -56,8 +57,16 @@ typedef struct {
  *                 rounded to bf16 (nearest even); weights packed as bf16
  *                 [mt][chunk][tap][kstep][64 lanes][8], lane l holding row l & 31, channels
  *                 chunk*ck_bf16 + 16*kstep + 8*(l >> 5) .. +7.                                */
-#define VK_PREC_F32   0
-#define VK_PREC_BF16  1
+#define VK_PREC_F32        0
+#define VK_PREC_BF16       1
+/*   VK_PREC_F32_SPLIT  fp32-accurate products on the bf16 matrix cores: every operand is cut
+ *                 exactly into three bf16 slices hi + mid + lo (each the rounded remainder) and a product
+ *                 is the six slice products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid
+ *                 accumulated in fp32; the dropped terms are < 2^-26 of the product.  Weights
+ *                 packed as bf16 [mt][chunk][tap][kstep][slice][64 lanes][8], chunk = 16
+ *                 channels (ck_split), lane l holding row l & 31, channels
+ *                 chunk*16 + 8*(l >> 5) .. +7 of slice hi / mid / lo.                          */
+#define VK_PREC_F32_SPLIT  2
 
 /* Tile families (vk_conv_args.tile). */
 #define VK_TILE_M128  0   /* 128 rows x 128 cols, 4 waves split rows        (C_out >= 128) */
@@ -105,7 +114,7 @@ typedef struct {
     int32_t hidden;       /* VK_EPI_WN_MID: rows < hidden are the residual half */
     int32_t up_stride;    /* VK_EPI_UPSAMPLE: stride S (kernel 2S, padding S/2) */
     float   navg;         /* VK_EPI_RESID_AVG divisor */
-    int32_t precision;    /* VK_PREC_F32 or VK_PREC_BF16 (selects the packed weight format too) */
+    int32_t precision;    /* VK_PREC_* (selects the packed weight format too) */
 } vk_conv_args;
 
 int         vk_abi_version(void);

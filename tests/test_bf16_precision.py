@@ -74,6 +74,40 @@ def test_bf16_decoder_tts_and_vc(sd, golden_dir, bf16_mode):
     _report(wav, g9["wav"], "bf16 voice conversion")
 
 
+def test_split_mode_meets_the_fp32_contract(sd, golden_dir):
+    """fp32 operands as three exact bf16 slices (six slice products, fp32 accumulation): held to
+    the fp32 path's own bars, 1e-4 max-abs on the waveform and 2e-5 relative internally."""
+    from oracle import vits_oracle as O
+    engine.set_precision("fp32-split")
+    try:
+        g1 = _gold(golden_dir, "g1_decoder.npz")
+        dec = Decoder(256)
+        dec.load_state_dict(synth.strip_prefix(sd, "decoder"), strict=True)
+        dec = dec.to(DEV).eval()
+        z = synth.latent(SEED, "g1.z", 2, 24)
+        spk = O.speaker_embed(torch.tensor([9, 57]), sd)
+        gen = HotPathGenerator(100)
+        gen.load_state_dict(sd, strict=True)
+        gen = gen.to(DEV).eval()
+        g7 = _gold(golden_dir, "g7_posterior.npz")
+        g9 = _gold(golden_dir, "g9_vc.npz")
+        spec = synth.power_spectrogram(SEED, "g7.spec", 2, 40)
+        cases = [("decoder", dec(z.to(DEV), spk.to(DEV)), g1["wav"]),
+                 ("voice conversion", gen.voice_conversion(spec.to(DEV), g7["lengths"].to(DEV), g9["src"].to(DEV),
+                                                           g9["tgt"].to(DEV), noise=g7["eps"].to(DEV)), g9["wav"])]
+        zl = synth.latent(SEED, "split.z", 2, 300)
+        gl = O.speaker_embed(torch.tensor([3, 71]), sd)
+        cases.append(("decoder T=300", dec(zl.to(DEV), gl.to(DEV)), O.decoder(zl, gl, sd)))
+        for what, got, ref in cases:
+            got = got.cpu()
+            err = (got - ref).abs().max().item()
+            print(f"fp32-split {what}: max-abs {err:.3e} (|ref|max {ref.abs().max().item():.3f})")
+            assert torch.isfinite(got).all()
+            assert err <= 1e-4 and err <= 2e-5 * max(1.0, ref.abs().max().item()), (what, err)
+    finally:
+        engine.set_precision("fp32")
+
+
 def test_precision_switch_rebuilds_plans(sd, golden_dir):
     """The same module object serves both precisions; switching back restores the fp32 result."""
     g1 = _gold(golden_dir, "g1_decoder.npz")

@@ -346,3 +346,58 @@ def test_bf16_fused_resblock_pair(ch, k, dil, B, L):
     native.conv1d(tmp, _pack16(w2, tile), two, c_in=ch, c_out=ch, taps=k, dilation=1, pad=(k - 1) // 2,
                   tile=tile, epilogue=native.EPI_RESID, bias=b2.to(DEV), res=xd, act_in=True, in_slope=0.1)
     assert (two - out).abs().max().item() <= 2e-3
+
+
+# ---- fp32 operands as three bf16 slices: fp32-level accuracy, same tolerance as the fp32 kernel
+def _pack_split(w, tile, row_order=None):
+    ti = native.tile_info(tile)
+    return packing.pack_conv_weight_split(w.to(DEV), ti.ck_split, ti.rows_per_block, row_order)
+
+
+def test_split3_is_exact():
+    w = _rand(4096, seed=101) * torch.logspace(-6, 3, 4096)
+    hi, mid, lo = packing.split3(w)
+    assert torch.equal(hi + mid + lo, w) and torch.equal((hi + mid) + lo, w)
+    for s in (hi, mid, lo):
+        assert torch.equal(s.to(torch.bfloat16).to(torch.float32), s)
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,B,L,act", [
+    (32, 32, 3, 1, 1, 1, True),
+    (32, 32, 11, 5, 2, 37, True),
+    (64, 64, 7, 3, 3, 517, True),
+    (128, 128, 3, 5, 2, 1000, True),
+    (256, 256, 11, 1, 1, 260, True),
+    (192, 512, 7, 1, 2, 45, False),
+    (513, 192, 1, 1, 1, 50, False),
+    (40, 72, 5, 2, 2, 130, True),
+])
+def test_split_conv_matches_fp32(cin, cout, k, dil, B, L, act):
+    x = _rand(B, cin, L, seed=111)
+    w = _rand(cout, cin, k, seed=112) / (cin * k) ** 0.5
+    bias = _rand(B, cout, seed=113)
+    res = _rand(B, cout, L, seed=114)
+    pad = (k - 1) * dil // 2
+    xin = F.leaky_relu(x, 0.1) if act else x
+    ref = (F.conv1d(xin.double(), w.double(), None, padding=pad, dilation=dil) + bias.unsqueeze(-1).double())
+    tile = choose_tile(cout)
+    wp = _pack_split(w, tile)
+    out = torch.full((B, cout, L), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), wp, out, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                  epilogue=native.EPI_STORE, bias=bias.to(DEV), bias_bstride=cout, act_in=act, in_slope=0.1)
+    err = (out.cpu().double() - ref).abs().max().item()
+    # yardsticks against the same fp64 result: PyTorch's fp32 convolution on the CPU and this
+    # library's own fp32 matrix-core kernel (one long fp32 accumulation chain, like the split one)
+    cpu_err = (F.conv1d(xin, w, None, padding=pad, dilation=dil) + bias.unsqueeze(-1)).double().sub(ref).abs().max().item()
+    out32 = torch.full((B, cout, L), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), _pack(w, tile), out32, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                  epilogue=native.EPI_STORE, bias=bias.to(DEV), bias_bstride=cout, act_in=act, in_slope=0.1)
+    mfma_err = (out32.cpu().double() - ref).abs().max().item()
+    print(f"max-abs vs fp64: split {err:.2e}, fp32 MFMA kernel {mfma_err:.2e}, PyTorch CPU fp32 {cpu_err:.2e}")
+    assert err <= max(2.0 * mfma_err, 4.0 * cpu_err, 1e-6), (err, mfma_err, cpu_err)
+    if act:
+        out2 = torch.full((B, cout, L), float("nan"), device=DEV)
+        native.conv1d(x.to(DEV), wp, out2, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                      epilogue=native.EPI_RESID, bias=bias.to(DEV), bias_bstride=cout, res=res.to(DEV),
+                      act_in=True, in_slope=0.1)
+        _close(out2, (ref + res.double()).float(), "split residual")

@@ -7,6 +7,7 @@
 #include "resblock_pair.hpp"
 #include "conv_bf16.hpp"
 #include "resblock_pair_bf16.hpp"
+#include "conv_split.hpp"
 #include "api_internal.hpp"
 
 static thread_local char g_err[512] = "";
@@ -33,6 +34,7 @@ extern "C" int vk_tile_query(int tile, vk_tile_info* info)
     info->time_tile = 32 * G.b_rep * G.wn;
     info->a_rep = G.a_rep;
     info->ck_bf16 = kBf16Ck[tile];
+    info->ck_split = VK_SPLIT_CK;
     return VK_OK;
 }
 
@@ -53,9 +55,10 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     if (a->tile < 0 || a->tile >= VK_TILE_COUNT) return vk_fail(VK_E_ARG, "vk_conv1d: bad tile id");
     if (a->epilogue < 0 || a->epilogue >= VK_EPI_COUNT) return vk_fail(VK_E_ARG, "vk_conv1d: bad epilogue id");
     if (a->batch > 65535) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: batch > 65535");
-    if (a->precision != VK_PREC_F32 && a->precision != VK_PREC_BF16) return vk_fail(VK_E_ARG, "vk_conv1d: bad precision id");
-    const bool bf16 = a->precision == VK_PREC_BF16;
-    const TileGeom& G = kTiles[a->tile];
+    if (a->precision < VK_PREC_F32 || a->precision > VK_PREC_F32_SPLIT) return vk_fail(VK_E_ARG, "vk_conv1d: bad precision id");
+    const bool split = a->precision == VK_PREC_F32_SPLIT;
+    const bool bf16 = a->precision == VK_PREC_BF16 || split;      // bf16 matrix instructions, channel-minor LDS tile
+    const TileGeom& G = split ? kSplitTiles[a->tile] : kTiles[a->tile];
     const int TN = 32 * G.b_rep * G.wn;
     const bool ups = a->epilogue == VK_EPI_UPSAMPLE;
     const int halo = (a->taps - 1) * a->dilation + (ups ? 1 : 0);
@@ -106,7 +109,7 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     memset(d, 0, sizeof(*d));
     d->a = *a;
     d->x_bytes = (unsigned)xb; d->out_bytes = (unsigned)ob; d->res_bytes = (unsigned)rb; d->out2_bytes = (unsigned)o2;
-    const int ck = bf16 ? kBf16Ck[a->tile] : G.ck;
+    const int ck = split ? VK_SPLIT_CK : (bf16 ? kBf16Ck[a->tile] : G.ck);
     d->nchunk = (a->c_in + ck - 1) / ck;
     // 16-byte staging when every row of x starts 16-byte aligned and the length is a multiple of 4
     static const int no_vec = getenv("VK_NO_VEC") != nullptr;
@@ -125,14 +128,14 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     d->lds_stride = TN + 64;              // compile-time constant of the kernel
     if (d->xw > d->lds_stride)
         return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: time tile + halo does not fit the staged LDS row");
-    d->groups_per_mt = d->nchunk * a->taps * (bf16 ? ck / 16 : ck / 8);
+    d->groups_per_mt = d->nchunk * a->taps * (split ? 3 * (ck / 16) : (bf16 ? ck / 16 : ck / 8));
     static const int dbg = getenv("VK_DEBUG_SKIP") ? atoi(getenv("VK_DEBUG_SKIP")) : 0;
     d->dbg = dbg;
     d->stamps = g_stamps;
     const int rows_blk = 32 * G.a_rep * G.wm;
     const int64_t rows = gemm_rows(a);
     *grid = dim3((unsigned)((a->length + TN - 1) / TN), (unsigned)((rows + rows_blk - 1) / rows_blk), (unsigned)a->batch);
-    *lds = bf16 ? (size_t)2 * (TN + 64) * (ck * 2 + 16) : (size_t)2 * G.ck * d->lds_stride * sizeof(float);
+    *lds = bf16 ? (size_t)2 * (TN + 64) * ((split ? 3 : 1) * ck * 2 + 16) : (size_t)2 * G.ck * d->lds_stride * sizeof(float);
     static const int lds_min = getenv("VK_LDS_MIN") ? atoi(getenv("VK_LDS_MIN")) : 0;   // occupancy experiments
     if ((int)*lds < lds_min) *lds = lds_min;
     if (*lds > 160 * 1024) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: LDS tile exceeds 160 KiB");
@@ -154,7 +157,14 @@ extern "C" int vk_conv1d(const vk_conv_args* a, void* stream)
     hipStream_t s = (hipStream_t)stream;
     const int act = a->act_in ? 1 : 0;
     int e = -1;
-    if (a->precision == VK_PREC_BF16) {
+    if (a->precision == VK_PREC_F32_SPLIT) {
+        switch (a->tile) {
+        case VK_TILE_M128: e = vk_launch_split_tile0(a->epilogue, act, d, grid, lds, s); break;
+        case VK_TILE_M64:  e = vk_launch_split_tile1(a->epilogue, act, d, grid, lds, s); break;
+        case VK_TILE_M32:  e = vk_launch_split_tile2(a->epilogue, act, d, grid, lds, s); break;
+        case VK_TILE_PAIR: e = vk_launch_split_tile3(a->epilogue, act, d, grid, lds, s); break;
+        }
+    } else if (a->precision == VK_PREC_BF16) {
         switch (a->tile) {
         case VK_TILE_M128: e = vk_launch_bf16_tile0(a->epilogue, act, d, grid, lds, s); break;
         case VK_TILE_M64:  e = vk_launch_bf16_tile1(a->epilogue, act, d, grid, lds, s); break;
@@ -194,7 +204,7 @@ extern "C" int vk_pair_query(int channels, int precision, vk_tile_info* info)
     if (precision == VK_PREC_BF16) {
         const PairGeomBf16* G = pair_geom_bf16(channels);
         if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_pair_query: no fused bf16 kernel for this channel count");
-        info->ck = 0; info->ck_bf16 = 32;
+        info->ck = 0; info->ck_bf16 = 32; info->ck_split = 0;
         info->rows_per_block = 32 * G->a_rep * G->wm;
         info->time_tile = 32 * G->b_rep * G->wn - VK_PAIR_OVERLAP;
         info->a_rep = G->a_rep;
@@ -207,6 +217,7 @@ extern "C" int vk_pair_query(int channels, int precision, vk_tile_info* info)
     info->time_tile = 32 * G->b_rep * G->wn - VK_PAIR_OVERLAP;
     info->a_rep = 1;
     info->ck_bf16 = 0;
+    info->ck_split = 0;
     return VK_OK;
 }
 

@@ -1,0 +1,34 @@
+// bf16-sliced fp32 instantiations of tile family 1.
+#include "conv_launch.hpp"
+#include "conv_split.hpp"
+
+#define VK_SPLIT_CASE(EPI, ACT)                                                                   \
+    if (epi == (EPI) && act == (ACT)) {                                                          \
+        auto k = conv_split_kernel<G.a_rep, G.b_rep, G.wm, G.wn, CKB, (EPI), (ACT) != 0>;         \
+        static size_t lds_allowed = 65536;                                                       \
+        if (lds > lds_allowed) {                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return (int)e;                                                  \
+            lds_allowed = 160 * 1024;                                                            \
+        }                                                                                        \
+        hipLaunchKernelGGL(k, grid, dim3(64 * G.wm * G.wn), lds, s, d);                          \
+        return (int)hipGetLastError();                                                           \
+    }
+
+int vk_launch_split_tile1(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s)
+{
+    constexpr TileGeom G = kSplitTiles[1];
+    constexpr int CKB = VK_SPLIT_CK;
+    VK_SPLIT_CASE(VK_EPI_STORE, 0)
+    VK_SPLIT_CASE(VK_EPI_STORE, 1)
+    VK_SPLIT_CASE(VK_EPI_RESID, 1)
+    VK_SPLIT_CASE(VK_EPI_RESID_ACC, 1)
+    VK_SPLIT_CASE(VK_EPI_RESID_AVG, 1)
+    VK_SPLIT_CASE(VK_EPI_UPSAMPLE, 1)
+    VK_SPLIT_CASE(VK_EPI_WN_MID, 0)
+    VK_SPLIT_CASE(VK_EPI_WN_LAST, 0)
+    VK_SPLIT_CASE(VK_EPI_COUPLE_REV, 0)
+    VK_SPLIT_CASE(VK_EPI_COUPLE_FWD, 0)
+    return -1;
+}

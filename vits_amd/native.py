@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvits_amd.so")
 
 TILE_M128, TILE_M64, TILE_M32, TILE_PAIR = 0, 1, 2, 3
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F32_SPLIT = 0, 1, 2
 (EPI_STORE, EPI_RESID, EPI_RESID_ACC, EPI_RESID_AVG, EPI_GATE, EPI_WN_MID, EPI_WN_LAST,
  EPI_COUPLE_REV, EPI_COUPLE_FWD, EPI_UPSAMPLE, EPI_SAMPLE) = range(11)
 
@@ -23,7 +23,8 @@ _fp = C.c_void_p
 
 class TileInfo(C.Structure):
     _fields_ = [("ck", C.c_int32), ("rows_per_block", C.c_int32),
-                ("time_tile", C.c_int32), ("a_rep", C.c_int32), ("ck_bf16", C.c_int32)]
+                ("time_tile", C.c_int32), ("a_rep", C.c_int32), ("ck_bf16", C.c_int32),
+                ("ck_split", C.c_int32)]
 
 
 class ConvArgs(C.Structure):
@@ -212,12 +213,13 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     a.act_in, a.in_slope = int(act_in), in_slope
     a.first, a.hidden, a.up_stride, a.navg = int(first), hidden, up_stride, navg
     # the packed weight format names the matrix-core input precision
+    # (packing.py tags sliced-fp32 streams, which are bf16 tensors too)
     assert w_packed.dtype in (torch.float32, torch.bfloat16)
-    precision = PREC_BF16 if w_packed.dtype == torch.bfloat16 else PREC_F32
+    precision = getattr(w_packed, "vk_precision", PREC_BF16 if w_packed.dtype == torch.bfloat16 else PREC_F32)
     a.precision = precision
     rows = c_out * up_stride if epilogue == EPI_UPSAMPLE else c_out
     flops = 2.0 * x.shape[0] * x.shape[2] * rows * c_in * taps
-    family = (f"conv_{'bf16' if precision == PREC_BF16 else 'mfma'}"
+    family = (f"conv_{('mfma', 'bf16', 'split')[precision]}"
               f"[{_TILE_NAMES[tile]},{_EPI_NAMES[epilogue]},act={int(act_in)}]")
     L = lib()
     sp = stream_ptr(x.device)

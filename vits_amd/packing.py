@@ -66,6 +66,43 @@ def pack_conv_weight_bf16(w: torch.Tensor, ck: int, rows_per_block: int, row_ord
     return torch.cat([flat, torch.zeros(8 * 512, dtype=torch.bfloat16, device=w.device)])
 
 
+def split3(w: torch.Tensor):
+    """Three-way split of fp32 values into bf16-representable slices with hi + mid + lo == w:
+    each slice is what is left, rounded to nearest even in bf16 (the last one is exact)."""
+    w = w.to(torch.float32)
+    hi = w.to(torch.bfloat16).to(torch.float32)
+    r1 = w - hi
+    mid = r1.to(torch.bfloat16).to(torch.float32)
+    lo = (r1 - mid).to(torch.bfloat16).to(torch.float32)
+    return hi, mid, lo
+
+
+def pack_conv_weight_split(w: torch.Tensor, ck: int, rows_per_block: int, row_order=None) -> torch.Tensor:
+    """w [rows, c_in, taps] -> flat bf16 tensor for the sliced-fp32 kernels (csrc/conv_split.hpp):
+
+        packed[mt][chunk][tap][kstep][slice][lane][i],  slice 0/1/2 = hi/mid/lo of
+        W[row(32*mt + (lane & 31)), chunk*CK + 16*kstep + 8*(lane >> 5) + i, tap]
+
+    The returned tensor carries ``vk_precision`` so the launcher picks the matching kernel."""
+    from . import native
+    w = w.detach().to(torch.float32)
+    if row_order is not None:
+        w = w[row_order]
+    rows, cin, taps = w.shape
+    rpad = -(-rows // rows_per_block) * rows_per_block
+    cpad = -(-cin // ck) * ck
+    wp = torch.zeros(rpad, cpad, taps, dtype=torch.float32, device=w.device)
+    wp[:rows, :cin] = w
+    mt, nch, ks = rpad // 32, cpad // ck, ck // 16
+    slices = torch.stack(split3(wp), 0)                                     # [3, rpad, cpad, taps]
+    # [s, mt, r, chunk, kstep, h, i, tap] -> [mt, chunk, tap, kstep, s, h, r, i]
+    sp = slices.view(3, mt, 32, nch, ks, 2, 8, taps).permute(1, 3, 7, 4, 0, 5, 2, 6).contiguous()
+    flat = sp.view(-1).to(torch.bfloat16)                                   # exact: slices have <= 8 significant bits
+    out = torch.cat([flat, torch.zeros(3 * 8 * 512, dtype=torch.bfloat16, device=w.device)])
+    out.vk_precision = native.PREC_F32_SPLIT
+    return out
+
+
 def pair_row_order(hidden: int) -> torch.Tensor:
     """Row order that interleaves 32-row tiles of the two halves of a 2*hidden-row output:
     [a0, b0, a1, b1, ...] with a_q = rows 32q.., b_q = rows hidden + 32q.."""
