@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp32-split"], default="fp32",
                     help="matrix-core input precision; fp32 is the <= 1e-4 parity path and the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-precisions", action="store_true",
+                    help="skip the short untimed-region runs of the other precision modes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
 
@@ -227,6 +229,26 @@ def main():
             "roofline": roof_fp32 if args.precision == "fp32" else roof,
             "per_gpu_value": value / world,
         }
+        if world == 1 and args.workload == "batch" and not args.no_other_precisions:
+            # the same step in the other matrix-core input modes (3 timed steps each), with the
+            # largest waveform difference from the timed mode's output
+            others = {}
+            ref_wav = wav
+            for prec in ("fp32", "fp32-split", "bf16"):
+                if prec == args.precision:
+                    continue
+                engine.set_precision(prec)
+                w2 = step()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    w2 = step()
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t1) / 3
+                others[prec] = {"ms_per_step": 1e3 * dt, "value": total_frames * HOP / SAMPLE_RATE / dt,
+                                "max_abs_diff_vs_timed_mode": float((w2 - ref_wav).abs().max().item())}
+            engine.set_precision(args.precision)
+            line["other_precisions"] = others
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth.hot_path_state_dict(SEED, with_posterior=False),
                                                 T, args.cpu_seconds)

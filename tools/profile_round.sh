@@ -8,8 +8,8 @@ shift || true
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o bench --output-format csv -- \
-    python3 bench.py --steps 5 --warmup 2 "$@" > gpurun_out/${tag}_bench_under_rocprof.json
+    python3 bench.py --steps 5 --warmup 2 --no-other-precisions "$@" > gpurun_out/${tag}_bench_under_rocprof.json
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch -o fetch --output-format csv -- \
-    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > /dev/null
+    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-precisions "$@" > /dev/null
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${tag}_write -o write --output-format csv -- \
-    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > /dev/null
+    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-precisions "$@" > /dev/null

@@ -187,15 +187,19 @@ conv_split_kernel(const ConvDev d)
         __syncthreads();
         if (chunk + 1 < d.nchunk) stg.issue(d, chunk + 1);
 
+        // B fragments rotate in place: as soon as the six products of a column tile have been
+        // issued, its three fragment registers are reloaded for the next k-step, so every LDS
+        // read has the other column tiles' MFMAs to land behind.  Weights, which come from L2,
+        // are fetched one tap ahead.
         const char* bt = buf + bcol;
         bf16x8 bf[3][B_REP];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int n = 0; n < B_REP; ++n)
 #pragma unroll
-            for (int n = 0; n < B_REP; ++n) bf[s][n] = *reinterpret_cast<const bf16x8*>(bt + s * PLANE + n * 32 * PITCH);
+            for (int s = 0; s < 3; ++s) bf[s][n] = *reinterpret_cast<const bf16x8*>(bt + s * PLANE + n * 32 * PITCH);
 #pragma unroll 1
         for (int tap = 0; tap < p.taps; ++tap) {
-            const char* bt_next = (tap + 1 < p.taps) ? bt + tap_step : buf + bcol;
+            const char* bt_next = (tap + 1 < p.taps) ? bt + tap_step : buf + bcol;   // chunk end: harmless re-read
             bf16x8 a_nxt[KS][3][A_REP];
 #pragma unroll
             for (int k = 0; k < KS; ++k)
@@ -205,19 +209,11 @@ conv_split_kernel(const ConvDev d)
                     for (int m = 0; m < A_REP; ++m) a_nxt[k][s][m] = aptr[m][64 * (3 * (KS + k) + s)];
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
-                bf16x8 bn[3][B_REP];
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int n = 0; n < B_REP; ++n) {
+                    // smallest terms first
 #pragma unroll
-                    for (int n = 0; n < B_REP; ++n)
-                        bn[s][n] = (k + 1 < KS)
-                            ? *reinterpret_cast<const bf16x8*>(bt + s * PLANE + n * 32 * PITCH + (k + 1) * 32)
-                            : *reinterpret_cast<const bf16x8*>(bt_next + s * PLANE + n * 32 * PITCH);
-                // smallest terms first
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m)
-#pragma unroll
-                    for (int n = 0; n < B_REP; ++n) {
+                    for (int m = 0; m < A_REP; ++m) {
                         f32x16 c = acc[m][n];
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k][2][m], bf[0][n], c, 0, 0, 0);   // lo  * hi
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k][0][m], bf[2][n], c, 0, 0, 0);   // hi  * lo
@@ -227,10 +223,13 @@ conv_split_kernel(const ConvDev d)
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k][0][m], bf[0][n], c, 0, 0, 0);   // hi  * hi
                         acc[m][n] = c;
                     }
+                    const char* nx = (k + 1 < KS) ? bt + (k + 1) * 32 : bt_next;
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int n = 0; n < B_REP; ++n) bf[s][n] = bn[s][n];
+                    for (int s = 0; s < 3; ++s)
+                        bf[s][n] = *reinterpret_cast<const bf16x8*>(nx + s * PLANE + n * 32 * PITCH);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6 * A_REP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                }
             }
             bt = bt_next;
 #pragma unroll
