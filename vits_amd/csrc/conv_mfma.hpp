@@ -559,12 +559,6 @@ conv_mfma_kernel(const ConvDev d)
 #pragma unroll 1
         for (int tap = 0; tap < p.taps; ++tap) {
             const float* bt_next = (tap + 1 < p.taps) ? bt + p.dilation : buf + bcol;   // chunk end: harmless re-read
-            float4 a_nxt[GPC][A_REP];
-#pragma unroll
-            for (int g = 0; g < GPC; ++g)
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m) a_nxt[g][m] = aptr[m][64 * (GPC + g)];
-            __builtin_amdgcn_sched_group_barrier(0x020, GPC * A_REP, 0);
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
                 float4 a_cur[A_REP];
@@ -591,14 +585,15 @@ conv_mfma_kernel(const ConvDev d)
                     __builtin_amdgcn_sched_group_barrier(0x100, (B_REP + 1) / 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, A_REP * B_REP, 0);
                 }
+                // this group's registers are dead now: refill them in place with the next tap's
+                // group; the other groups' MFMAs of this tap and the next cover the L2 latency
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a[g][m] = aptr[m][64 * (GPC + g)];
+                __builtin_amdgcn_sched_group_barrier(0x020, A_REP, 0);
             }
             bt = bt_next;
 #pragma unroll
             for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * GPC;
-#pragma unroll
-            for (int g = 0; g < GPC; ++g)
-#pragma unroll
-                for (int m = 0; m < A_REP; ++m) a[g][m] = a_nxt[g][m];
         }
     }
 
