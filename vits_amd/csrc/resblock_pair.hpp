@@ -131,8 +131,8 @@ resblock_pair_kernel(const PairDev q)
             for (int r = 0; r < 16; ++r) acc[n][r] = bv[r];
     }
 
-    // The k-loop of one staged chunk: taps outermost, channel pairs inside, weights fetched one
-    // tap ahead, B fragments of the next k-step read before the current k-step's MFMAs.
+    // The k-loop of one staged chunk: taps outermost, channel pairs inside, each weight group
+    // refetched for the next tap right after its last use, B fragments of the next k-step read before the current k-step's MFMAs.
     auto run_chunk = [&](const float* base, int taps, int dilation) {
         const float* bt = base;
         float bf[B_REP];
@@ -141,10 +141,6 @@ resblock_pair_kernel(const PairDev q)
 #pragma unroll 1
         for (int tap = 0; tap < taps; ++tap) {
             const float* bt_next = (tap + 1 < taps) ? bt + dilation : base;
-            float4 a_nxt[GPC];
-#pragma unroll
-            for (int g = 0; g < GPC; ++g) a_nxt[g] = aptr[64 * (GPC + g)];
-            __builtin_amdgcn_sched_group_barrier(0x020, GPC, 0);
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
                 const float4 a_cur = a[g];
@@ -165,11 +161,11 @@ resblock_pair_kernel(const PairDev q)
                     __builtin_amdgcn_sched_group_barrier(0x100, (B_REP + 1) / 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, B_REP, 0);
                 }
+                a[g] = aptr[64 * (GPC + g)];        // refilled in place for the next tap
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             bt = bt_next;
             aptr += 64 * GPC;
-#pragma unroll
-            for (int g = 0; g < GPC; ++g) a[g] = a_nxt[g];
         }
     };
 
