@@ -140,8 +140,9 @@ class LaunchTimer:
 
     active = None
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []          # (family, flops, bytes, start_event, end_event, detail)
+        self.only = only           # optional set of family names: other launches are not bracketed
 
     def __enter__(self):
         LaunchTimer.active = self
@@ -164,7 +165,7 @@ class LaunchTimer:
 
 def _timed(family, flops, nbytes, device, launch, detail=""):
     t = LaunchTimer.active
-    if t is None:
+    if t is None or (t.only is not None and family not in t.only):
         return launch()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
