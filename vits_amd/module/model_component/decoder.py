@@ -68,7 +68,7 @@ class ResBlockPlan:
                                    PackedConv(c2.effective_weight(), c2.bias, device, dilation=1)))
         self.taps = k
 
-    def _run_fused(self, x, tmp, run_buf, final_out, final_epi, acc_in, navg):
+    def _run_fused(self, x, tmp, run_buf, final_out, final_epi, acc_in, navg, before_final=None):
         # pairs ping-pong between the two scratch buffers: a pair's output may not land on its
         # input, whose halo columns neighbouring workgroups still read
         cur = x
@@ -82,17 +82,20 @@ class ResBlockPlan:
             else:
                 if final_out.data_ptr() == cur.data_ptr():
                     raise native.NativeError("resblock: the output buffer aliases the last pair's input")
+                if before_final is not None:
+                    before_final()
                 native.resblock_pair(cur, w1, b1, w2, b2, final_out, taps=self.taps, dilation=d,
                                      epilogue=final_epi, slope=LRELU_SLOPE, acc=acc_in, navg=navg)
         return final_out
 
-    def run(self, x, tmp, run_buf, final_out, final_epi, acc_in=None, navg=1.0):
+    def run(self, x, tmp, run_buf, final_out, final_epi, acc_in=None, navg=1.0, before_final=None):
         """x -> resblock(x).  The last conv writes ``final_out`` with ``final_epi`` (plain
         residual, or residual + accumulation over resblocks); earlier pairs update ``run_buf``
-        (and ``tmp``)."""
+        (and ``tmp``).  ``before_final`` is called just before the launch that touches
+        ``final_out`` / ``acc_in`` (where a concurrent branch orders itself after its predecessor)."""
         if self.fused:
             return self._run_fused(x, tmp, run_buf, final_out, final_epi,
-                                   acc_in if final_epi != native.EPI_RESID else None, navg)
+                                   acc_in if final_epi != native.EPI_RESID else None, navg, before_final)
         C = x.shape[1]
         cur = x
         last = len(self.pairs) - 1
@@ -106,6 +109,8 @@ class ResBlockPlan:
                               act_in=True, in_slope=LRELU_SLOPE)
                 cur = run_buf
             else:
+                if before_final is not None:
+                    before_final()
                 native.conv1d(tmp, c2.w, final_out, c_in=C, c_out=C, taps=c2.taps, dilation=1, pad=c2.pad,
                               tile=c2.tile, epilogue=final_epi, bias=c2.bias, res=cur, out2=acc_in,
                               act_in=True, in_slope=LRELU_SLOPE, navg=navg)
@@ -147,6 +152,7 @@ class DecoderPlan:
             poly = packing.transposed_to_polyphase(wt, s)
             self.ups.append((PackedConv(poly, up.bias, device, pad=1), s, wt.shape[1]))
         self.resblocks = [rb.plan(device) for rb in dec.resblocks]
+        self.side_streams = None            # created on first use by a small-batch forward
         self.post_w = dec.conv1d_post.weight.detach().to(device)[0].contiguous()    # [C, taps]
 
 
@@ -183,6 +189,44 @@ class Decoder(nn.Module):
         self.conv1d_post = PlainConvParams(ch, 1, 7, bias=False)
         self._plans = PlanCache(self, lambda dev: DecoderPlan(self, dev))
 
+    # The resblocks of a stage are independent until their last convolution adds into the stage
+    # output.  With few utterances in flight one convolution does not fill 256 CUs, so each
+    # resblock then runs on a stream of its own; the last launches are chained by events in the
+    # reference's summation order (decoder.py:119-125), which keeps the result bit-identical.
+    concurrent_branch_frames = 2048         # use branch streams when batch * frames is at most this
+
+    def _branches_concurrent(self, batch, frames):
+        mode = os.environ.get("VITS_AMD_BRANCH_STREAMS", "auto")
+        if mode in ("0", "off"):
+            return False
+        return mode in ("1", "on") or batch * frames <= self.concurrent_branch_frames
+
+    def _run_branches_concurrently(self, plan, stage, xu, xs, epis):
+        nrb = self.num_resnet_blocks
+        main = torch.cuda.current_stream(xu.device)
+        if plan.side_streams is None or len(plan.side_streams) < nrb - 1:
+            plan.side_streams = [torch.cuda.Stream(device=xu.device) for _ in range(nrb - 1)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        prev_done = None
+        for j in range(nrb):
+            stream = main if j == 0 else plan.side_streams[j - 1]
+            if j > 0:
+                stream.wait_event(fork)
+            with torch.cuda.stream(stream):
+                tmp, run_buf = torch.empty_like(xu), torch.empty_like(xu)
+                if stream is not main:              # the caching allocator must not hand these out
+                    tmp.record_stream(stream)       # again before this stream is done with them
+                    run_buf.record_stream(stream)
+                    xu.record_stream(stream)
+                    xs.record_stream(stream)
+                wait = (lambda e=prev_done, st=stream: st.wait_event(e)) if prev_done is not None else None
+                plan.resblocks[stage * nrb + j].run(xu, tmp, run_buf, xs, epis[j], acc_in=xs, navg=float(nrb),
+                                                    before_final=wait)
+                prev_done = torch.cuda.Event()
+                prev_done.record(stream)
+        main.wait_event(prev_done)
+
     @torch.no_grad()
     def forward(self, z, speaker_id_embedded):
         require_device(z, "Decoder.forward")
@@ -210,19 +254,16 @@ class Decoder(nn.Module):
             native.conv1d(x, up.w, xu, c_in=cin, c_out=cout, taps=2, dilation=1, pad=1, tile=up.tile,
                           epilogue=native.EPI_UPSAMPLE, bias=up.bias, act_in=True, in_slope=LRELU_SLOPE,
                           up_stride=s)
-            tmp = torch.empty_like(xu)
-            run_buf = torch.empty_like(xu)
             xs = torch.empty_like(xu)
-            for j in range(nrb):
-                if nrb == 1:
-                    epi = native.EPI_RESID
-                elif j == 0:
-                    epi = native.EPI_RESID
-                elif j < nrb - 1:
-                    epi = native.EPI_RESID_ACC
-                else:
-                    epi = native.EPI_RESID_AVG
-                plan.resblocks[i * nrb + j].run(xu, tmp, run_buf, xs, epi, acc_in=xs, navg=float(nrb))
+            epis = [native.EPI_RESID] + [native.EPI_RESID_ACC] * (nrb - 2) + [native.EPI_RESID_AVG] if nrb > 1 \
+                else [native.EPI_RESID]
+            if self._branches_concurrent(B, T) and nrb > 1:
+                self._run_branches_concurrently(plan, i, xu, xs, epis)
+            else:
+                tmp = torch.empty_like(xu)
+                run_buf = torch.empty_like(xu)
+                for j in range(nrb):
+                    plan.resblocks[i * nrb + j].run(xu, tmp, run_buf, xs, epis[j], acc_in=xs, navg=float(nrb))
             x = xs
         wav = torch.empty(B, 1, L, device=dev, dtype=torch.float32)
         native.post_conv_tanh(x, plan.post_w, wav, 0.01)
