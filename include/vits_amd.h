@@ -115,6 +115,8 @@ typedef struct {
     int32_t up_stride;    /* VK_EPI_UPSAMPLE: stride S (kernel 2S, padding S/2) */
     float   navg;         /* VK_EPI_RESID_AVG divisor */
     int32_t precision;    /* VK_PREC_* (selects the packed weight format too) */
+    int32_t narrow;       /* 1: half the family's time tile (twice the workgroups, same packed weights);
+                             for launches too small to fill the GPU.  VK_PREC_F32 only, ignored otherwise */
 } vk_conv_args;
 
 int         vk_abi_version(void);

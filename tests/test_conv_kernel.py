@@ -13,6 +13,16 @@ DEV = "cuda:0"
 TOL = 2e-5
 
 
+@pytest.fixture(params=["wide", "narrow"], autouse=True)
+def time_tile_width(request):
+    """Every kernel test runs with the families' full time tiles and with their half-width
+    variants (which the launcher otherwise picks by grid size)."""
+    saved = native.NARROW_BELOW_BLOCKS
+    native.NARROW_BELOW_BLOCKS = 0 if request.param == "wide" else 1 << 30
+    yield request.param
+    native.NARROW_BELOW_BLOCKS = saved
+
+
 def _rand(*shape, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g)

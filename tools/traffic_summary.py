@@ -38,7 +38,8 @@ for k, v in list(out.items())[:25]:
 
 # The same figures keyed by the kernel family names bench.py reports
 # (conv_mfma_kernel<A_REP, B_REP, WM, WN, CK, EPI, ACT, VEC> -> "conv_mfma[tile,epilogue,act=..]").
-TILES = {("1", "4", "4", "1"): "m128", ("1", "4", "2", "2"): "m64", ("1", "4", "1", "4"): "m32", ("2", "2", "2", "2"): "pair"}
+TILES = {("1", "4", "4", "1"): "m128", ("1", "4", "2", "2"): "m64", ("1", "4", "1", "4"): "m32", ("2", "2", "2", "2"): "pair",
+         ("1", "2", "4", "1"): "m128n", ("1", "2", "2", "2"): "m64n", ("1", "2", "1", "4"): "m32n", ("2", "1", "2", "2"): "pairn"}
 EPIS = ["store", "resid", "resid_acc", "resid_avg", "gate", "wn_mid", "wn_last", "couple_rev", "couple_fwd",
         "upsample", "sample"]
 fams = {}

@@ -13,11 +13,24 @@ static constexpr TileGeom kTiles[VK_TILE_COUNT] = {
     {2, 2, 2, 2, 16},
 };
 
+// The same families with half the time tile (same rows, same K-chunk, so the same packed
+// weights): twice the workgroups for launches that would otherwise leave CUs without work.
+static constexpr TileGeom kTilesNarrow[VK_TILE_COUNT] = {
+    {1, 2, 4, 1, 16},
+    {1, 2, 2, 2, 16},
+    {1, 2, 1, 4, 16},
+    {2, 1, 2, 2, 16},
+};
+
 // Returns hipSuccess / a HIP error, or -1 when (epilogue, act_in) is not built for the tile.
 int vk_launch_tile0(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
 int vk_launch_tile1(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
 int vk_launch_tile2(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
 int vk_launch_tile3(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile0n(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile1n(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile2n(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_tile3n(int epi, int act, int vec, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
 
 #define VK_CONV_CASE(EPI, ACT, VEC)                                                              \
     if (epi == (EPI) && act == (ACT) && vec == (VEC)) {                                          \

@@ -44,7 +44,7 @@ class ConvArgs(C.Structure):
         ("act_in", C.c_int32), ("in_slope", C.c_float),
         ("first", C.c_int32), ("hidden", C.c_int32), ("up_stride", C.c_int32),
         ("navg", C.c_float),
-        ("precision", C.c_int32),
+        ("precision", C.c_int32), ("narrow", C.c_int32),
     ]
 
 
@@ -177,6 +177,8 @@ def _timed(family, flops, nbytes, device, launch, detail=""):
     return rc
 
 
+NARROW_BELOW_BLOCKS = int(os.environ.get("VITS_AMD_NARROW_BELOW", "1024"))     # default: 256 CUs x 4 resident workgroups
+
 _EPI_NAMES = ["store", "resid", "resid_acc", "resid_avg", "gate", "wn_mid", "wn_last",
               "couple_rev", "couple_fwd", "upsample", "sample"]
 _TILE_NAMES = ["m128", "m64", "m32", "pair"]
@@ -218,10 +220,15 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     assert w_packed.dtype in (torch.float32, torch.bfloat16)
     precision = getattr(w_packed, "vk_precision", PREC_BF16 if w_packed.dtype == torch.bfloat16 else PREC_F32)
     a.precision = precision
+    # launches with too few workgroups to fill the GPU take the family's half-width time tile
+    rows_all = c_out * up_stride if epilogue == EPI_UPSAMPLE else (2 * hidden if epilogue in (EPI_GATE, EPI_SAMPLE) else c_out)
+    ti = tile_info(tile)
+    blocks = -(-x.shape[2] // ti.time_tile) * -(-rows_all // ti.rows_per_block) * x.shape[0]
+    a.narrow = int(precision == PREC_F32 and blocks < NARROW_BELOW_BLOCKS)
     rows = c_out * up_stride if epilogue == EPI_UPSAMPLE else c_out
     flops = 2.0 * x.shape[0] * x.shape[2] * rows * c_in * taps
     family = (f"conv_{('mfma', 'bf16', 'split')[precision]}"
-              f"[{_TILE_NAMES[tile]},{_EPI_NAMES[epilogue]},act={int(act_in)}]")
+              f"[{_TILE_NAMES[tile]}{'n' if a.narrow else ''},{_EPI_NAMES[epilogue]},act={int(act_in)}]")
     L = lib()
     sp = stream_ptr(x.device)
     detail = f"B{x.shape[0]} L{x.shape[2]} {c_in}->{rows} k{taps} d{dilation}"
