@@ -197,3 +197,38 @@ def test_graph_replay_matches_eager(sd):
     out = graphed(z1.to(DEV), g1.to(DEV)).clone()
     assert torch.equal(out, dec(z1.to(DEV), g1.to(DEV)))
     _check(out, O.decoder(z1, g1, sd), what="graphed decoder vs oracle")
+
+
+def test_front_half_graph_replay_matches_eager():
+    """Token-level half (text encoder + duration predictor) captured into a HIP graph: same
+    waveform as the eager path, also when replayed with other tokens, speaker and noise."""
+    from vits_amd.module.vits_generator import VitsGenerator
+    gen = VitsGenerator(40, 100)
+    gen.load_state_dict(synth.full_state_dict(gen.state_dict(), SEED), strict=True)
+    gen = gen.to(DEV).eval()
+    n = len(synth.TTS_SENTENCE_IDS)
+    lens = torch.tensor([n], device=DEV)
+    cases = []
+    for seed, spk in ((1, 9), (2, 57)):
+        g = torch.Generator().manual_seed(seed)
+        ids = torch.tensor([synth.TTS_SENTENCE_IDS]) if seed == 1 else torch.randint(0, 40, (1, n), generator=g)
+        cases.append((ids.to(DEV), torch.tensor([spk], device=DEV), torch.randn(1, 2, n, generator=g).to(DEV)))
+    eager = []
+    for ids, spk, nw in cases:
+        m_p, logs_p, mask, gg = gen.frame_prior(ids, lens, spk, length_scale=3, noise_w=nw)
+        eager.append((m_p.clone(), logs_p.clone(), mask.clone()))
+    gen.use_front_graph = True
+    try:
+        for (ids, spk, nw), (m0, l0, k0) in zip(cases, eager):
+            m_p, logs_p, mask, gg = gen.frame_prior(ids, lens, spk, length_scale=3, noise_w=nw)
+            assert m_p.shape == m0.shape and torch.equal(mask, k0)
+            assert torch.equal(m_p, m0) and torch.equal(logs_p, l0)
+        assert len(gen._front_graphs) == 1
+        nz = torch.randn(1, 192, eager[0][0].shape[2], generator=torch.Generator().manual_seed(3)).to(DEV)
+        ids, spk, nw = cases[0]
+        a = gen.text_to_speech(ids, lens, spk, length_scale=3, noise_w=nw, noise_z=nz)
+        gen.use_front_graph = False
+        b = gen.text_to_speech(ids, lens, spk, length_scale=3, noise_w=nw, noise_z=nz)
+        assert torch.equal(a, b)
+    finally:
+        gen.use_front_graph = False

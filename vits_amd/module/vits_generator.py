@@ -8,6 +8,8 @@ decoder (:193-196) - runs on the HIP kernels.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -122,15 +124,48 @@ class VitsGenerator(HotPathGenerator):
     def forward(self, *args, **kwargs):
         raise NotImplementedError("training forward (vits_generator.py:127-166) is out of scope of the inference build")
 
-    @torch.no_grad()
-    def frame_prior(self, text_padded, text_lengths, speaker_id, length_scale=1, noise_scale_w=0.8, noise_w=None):
-        """Lines 169-182 of ``text_to_speech``: token-level prior, sampled durations, hard
-        monotonic path, frame-level (m_p, logs_p).  Returns (m_p, logs_p, spec_mask, g)."""
+    # The token-level half (text encoder, duration predictor) is some 400 tiny stock-PyTorch
+    # launches whose cost is host launch time (about 7.5 ms for one sentence against about 1.5 ms
+    # of GPU work).  With ``use_front_graph`` it is captured once per (batch, tokens, scales)
+    # into a HIP graph and replayed; everything after the durations has data-dependent shapes
+    # and stays eager.  VITS_AMD_FRONT_GRAPH=1 turns it on for every instance.
+    use_front_graph = os.environ.get("VITS_AMD_FRONT_GRAPH", "0") == "1"
+
+    def _token_stage(self, text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w):
+        """Lines 169-176 of ``text_to_speech``: token-level prior and sampled durations."""
         text_encoded, m_p, logs_p, text_mask = self.text_encoder(text_padded, text_lengths)
         g = self.embed_speaker(speaker_id)
         logw = self.stochastic_duration_predictor(text_encoded, text_mask, speaker_id_embedded=g, reverse=True,
                                                   noise_scale=noise_scale_w, noise=noise_w)
         w_ceil = torch.ceil(torch.exp(logw) * text_mask * length_scale)
+        return m_p, logs_p, text_mask, w_ceil, g
+
+    def _token_stage_graphed(self, text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w):
+        from ..graphs import GraphedCall
+        if not hasattr(self, "_front_graphs"):
+            self._front_graphs = {}
+        key = (tuple(text_padded.shape), str(text_padded.device), float(length_scale), float(noise_scale_w),
+               noise_w is not None)
+        call = self._front_graphs.get(key)
+        if call is None:
+            if noise_w is not None:
+                call = GraphedCall(lambda t, l, s, n: self._token_stage(t, l, s, n, length_scale, noise_scale_w),
+                                   text_padded, text_lengths, speaker_id, noise_w)
+            else:
+                call = GraphedCall(lambda t, l, s: self._token_stage(t, l, s, None, length_scale, noise_scale_w),
+                                   text_padded, text_lengths, speaker_id)
+            self._front_graphs[key] = call
+        args = (text_padded, text_lengths, speaker_id) + ((noise_w,) if noise_w is not None else ())
+        m_p, logs_p, text_mask, w_ceil, g = call(*args)
+        return m_p, logs_p, text_mask, w_ceil, g.clone()     # g outlives this call; the rest is consumed at once
+
+    @torch.no_grad()
+    def frame_prior(self, text_padded, text_lengths, speaker_id, length_scale=1, noise_scale_w=0.8, noise_w=None):
+        """Lines 169-182 of ``text_to_speech``: token-level prior, sampled durations, hard
+        monotonic path, frame-level (m_p, logs_p).  Returns (m_p, logs_p, spec_mask, g)."""
+        stage = self._token_stage_graphed if (self.use_front_graph and text_padded.is_cuda) else self._token_stage
+        m_p, logs_p, text_mask, w_ceil, g = stage(text_padded, text_lengths, speaker_id, noise_w, length_scale,
+                                                  noise_scale_w)
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
         spec_mask = torch.unsqueeze(sequence_mask(y_lengths, None), 1).to(text_mask.dtype)
         node_mask = torch.unsqueeze(text_mask, 2) * torch.unsqueeze(spec_mask, -1)
