@@ -160,6 +160,27 @@ typedef struct {
 int vk_pair_query(int channels, int precision, vk_tile_info* info);
 int vk_resblock_pair(const vk_pair_args* a, void* stream);
 
+/* ---- one whole layer of the WN gated stack in one launch ---------------------------
+ *   a = in_conv(x) + cond ; acts = tanh(a[:H]) * sigmoid(a[H:]) ; rs = res_skip(acts)
+ *   x_out = (x + rs[:H]) * mask ; skip (+)= rs[H:]         (wn.py:68-83)
+ *   last layer: out = (skip + rs) * mask                    (wn.py:85-86)
+ * acts stays in LDS.  fp32 only, hidden = 192 (vk_wn_query reports the packing geometry;
+ * other widths use two vk_conv1d launches).  x_out must not overlap x.                 */
+typedef struct {
+    const float* x;       int64_t x_bstride;    int64_t x_cstride;     /* layer input [B, H, L] */
+    const float* w_in;                                                 /* in-conv, rows in (a_q, b_q) pair order */
+    const float* cond;    int64_t cond_bstride;                        /* [B, 2H] conditioning + in-conv bias */
+    const float* w_rs;    const float* bias_rs;                        /* 1x1 conv (2H rows, H on the last layer) */
+    float* x_out;         int64_t xo_bstride;   int64_t xo_cstride;    /* (x + res) * mask; last layer: the output */
+    float* skip;          int64_t skip_bstride; int64_t skip_cstride;  /* running skip sum */
+    const float* mask;                                                 /* [B, L] */
+    int32_t batch, hidden, length, taps, dilation;
+    int32_t first, last;                                               /* first: skip starts at zero */
+} vk_wn_args;
+
+int vk_wn_query(int hidden, vk_tile_info* info);
+int vk_wn_layer(const vk_wn_args* a, void* stream);
+
 /* out[b, o] = bias[o] + sum_i W[o, i] * g[b, i]   (speaker-conditioning 1x1 convs on
  * [B, G, 1] inputs: decoder.py:91,112 `cond`; wn.py:41-42,66 `condition_layer`).
  * W is [n_out, n_in] row-major (weight norm already folded). One wavefront per output. */

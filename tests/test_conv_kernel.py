@@ -411,3 +411,43 @@ def test_split_conv_matches_fp32(cin, cout, k, dil, B, L, act):
                       epilogue=native.EPI_RESID, bias=bias.to(DEV), bias_bstride=cout, res=res.to(DEV),
                       act_in=True, in_slope=0.1)
         _close(out2, (ref + res.double()).float(), "split residual")
+
+
+@pytest.mark.parametrize("B,T,lens,dil", [(2, 50, (50, 21), 1), (3, 129, (129, 1, 77), 1), (1, 300, (300,), 2),
+                                          (16, 860, tuple(range(860, 700, -10)), 1)])
+def test_fused_wn_layer(B, T, lens, dil):
+    H, k = 192, 5
+    wi = native.wn_info(H)
+    assert wi is not None and native.wn_info(128) is None
+    mask = (torch.arange(T).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)).float()
+    x = _rand(B, H, T, seed=121)
+    w_in = _rand(2 * H, H, k, seed=122) / (H * k) ** 0.5
+    cond = _rand(B, 2 * H, seed=123)
+    w_rs = _rand(2 * H, H, 1, seed=124) / H ** 0.5
+    b_rs = _rand(2 * H, seed=125)
+    skip0 = _rand(B, H, T, seed=126)
+    a = F.conv1d(x, w_in, None, padding=(k - 1) * dil // 2, dilation=dil) + cond.unsqueeze(-1)
+    acts = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])
+    rs = F.conv1d(acts, w_rs, b_rs)
+    order = packing.pair_row_order(H)
+    p_in = packing.pack_conv_weight(w_in, wi.ck, wi.rows_per_block, order).to(DEV)
+    p_rs = packing.pack_conv_weight(w_rs, wi.ck, 32).to(DEV)
+    xd, md = x.to(DEV), mask.to(DEV)
+    for first in (True, False):
+        x_out = torch.full((B, H, T), float("nan"), device=DEV)
+        skip = skip0.to(DEV).clone()
+        native.wn_layer(xd, p_in, cond.to(DEV), 2 * H, p_rs, b_rs.to(DEV), x_out, skip, md,
+                        taps=k, dilation=dil, first=first, last=False)
+        _close(x_out, (x + rs[:, :H]) * mask.unsqueeze(1), "WN layer residual half")
+        _close(skip, rs[:, H:] if first else skip0 + rs[:, H:], "WN layer skip half")
+    # last layer: H output rows, out = (skip + rs) * mask
+    w_last = _rand(H, H, 1, seed=127) / H ** 0.5
+    p_last = packing.pack_conv_weight(w_last, wi.ck, 32).to(DEV)
+    out = torch.full((B, H, T), float("nan"), device=DEV)
+    skip = skip0.to(DEV).clone()
+    native.wn_layer(xd, p_in, cond.to(DEV), 2 * H, p_last, b_rs[:H].to(DEV), out, skip, md,
+                    taps=k, dilation=dil, first=False, last=True)
+    _close(out, (skip0 + F.conv1d(acts, w_last, b_rs[:H])) * mask.unsqueeze(1), "WN last layer")
+    with pytest.raises(native.NativeError):          # output on top of the input
+        native.wn_layer(xd, p_in, cond.to(DEV), 2 * H, p_rs, b_rs.to(DEV), xd, skip, md,
+                        taps=k, dilation=dil, first=True, last=False)

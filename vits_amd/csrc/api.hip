@@ -8,6 +8,7 @@
 #include "conv_bf16.hpp"
 #include "resblock_pair_bf16.hpp"
 #include "conv_split.hpp"
+#include "wn_layer.hpp"
 #include "api_internal.hpp"
 
 static thread_local char g_err[512] = "";
@@ -295,6 +296,79 @@ extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
     int e = bf16 ? vk_launch_pair_bf16(a->channels, a->epilogue, q, grid, lds, (hipStream_t)stream)
                  : vk_launch_pair(a->channels, a->epilogue, vec, q, grid, lds, (hipStream_t)stream);
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: this combination is not built");
+    if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
+    return VK_OK;
+}
+
+extern "C" int vk_wn_query(int hidden, vk_tile_info* info)
+{
+    if (!info || hidden != 32 * VK_WN_WAVES) return vk_fail(VK_E_UNSUPPORTED, "vk_wn_query: the fused WN layer is built for hidden = 192");
+    info->ck = VK_WN_CK;
+    info->rows_per_block = 64;
+    info->time_tile = 64;
+    info->a_rep = 2;
+    info->ck_bf16 = 0;
+    info->ck_split = 0;
+    return VK_OK;
+}
+
+extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
+{
+    if (!a) return vk_fail(VK_E_ARG, "vk_wn_layer: null argument block");
+    if (!a->x || !a->w_in || !a->cond || !a->w_rs || !a->x_out || !a->skip || !a->mask)
+        return vk_fail(VK_E_ARG, "vk_wn_layer: null pointer");
+    if (a->hidden != 32 * VK_WN_WAVES) return vk_fail(VK_E_UNSUPPORTED, "vk_wn_layer: built for hidden = 192");
+    if (a->batch <= 0 || a->batch > 65535 || a->length <= 0 || a->taps < 1 || a->dilation < 1)
+        return vk_fail(VK_E_ARG, "vk_wn_layer: bad size");
+    const int halo = (a->taps - 1) * a->dilation;
+    if (halo > 56 || (halo & 1)) return vk_fail(VK_E_UNSUPPORTED, "vk_wn_layer: (taps-1)*dilation must be even and at most 56");
+    if (a->x_cstride < 0 || a->xo_cstride < 0 || a->skip_cstride < 0) return vk_fail(VK_E_ARG, "vk_wn_layer: negative channel stride");
+    auto span = [&](int64_t cstride) -> int64_t { return ((int64_t)(a->hidden - 1) * cstride + a->length) * 4; };
+    const int64_t xb = span(a->x_cstride), ob = span(a->xo_cstride), sb = span(a->skip_cstride);
+    if (xb > 0x7fffffffLL || ob > 0x7fffffffLL || sb > 0x7fffffffLL)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_wn_layer: one batch item's view spans more than 2 GiB");
+    {
+        const char* x0 = (const char*)a->x;      const char* x1 = x0 + (int64_t)(a->batch - 1) * a->x_bstride * 4 + xb;
+        const char* o0 = (const char*)a->x_out;  const char* o1 = o0 + (int64_t)(a->batch - 1) * a->xo_bstride * 4 + ob;
+        if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_wn_layer: x_out overlaps x");
+    }
+    // 64-column windows unless that leaves most CUs without a workgroup
+    const int b_rep = ((int64_t)a->batch * ((a->length + 63) / 64) >= 512) ? 2 : 1;
+    const int TN = 32 * b_rep;
+    WnDev q;
+    memset(&q, 0, sizeof(q));
+    vk_conv_args& c = q.c.a;
+    c.x = a->x; c.x_bstride = a->x_bstride; c.x_cstride = a->x_cstride;
+    c.w = a->w_in; c.bias = a->cond; c.bias_bstride = a->cond_bstride;
+    c.out = a->x_out; c.out_bstride = a->xo_bstride; c.out_cstride = a->xo_cstride;
+    c.res = a->x; c.res_bstride = a->x_bstride; c.res_cstride = a->x_cstride;
+    c.out2 = a->skip; c.out2_bstride = a->skip_bstride; c.out2_cstride = a->skip_cstride;
+    c.mask = a->mask;
+    c.batch = a->batch; c.c_in = a->hidden; c.c_out = 2 * a->hidden; c.length = a->length;
+    c.taps = a->taps; c.dilation = a->dilation; c.pad = halo / 2;
+    c.first = a->first; c.hidden = a->hidden;
+    q.c.x_bytes = (unsigned)xb; q.c.out_bytes = (unsigned)ob; q.c.res_bytes = (unsigned)xb; q.c.out2_bytes = (unsigned)sb;
+    q.c.nchunk = a->hidden / VK_WN_CK;
+    static const int no_vec = getenv("VK_NO_VEC") != nullptr;
+    const int vec = !no_vec && ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) &&
+                    (a->length % 4 == 0);
+    if (vec) {
+        const int padv = (c.pad + 3) & ~3;
+        q.c.col0 = padv - c.pad;
+        q.c.xw = (TN + halo + q.c.col0 + 3) & ~3;
+    } else {
+        q.c.col0 = 0;
+        q.c.xw = TN + halo;
+    }
+    q.c.lds_stride = TN + 64;
+    q.c.groups_per_mt = q.c.nchunk * a->taps * (VK_WN_CK / 8);
+    q.w_rs = a->w_rs; q.bias_rs = a->bias_rs; q.groups_rs = q.c.nchunk * (VK_WN_CK / 8);
+    q.last = a->last;
+    dim3 grid((unsigned)((a->length + TN - 1) / TN), 1, (unsigned)a->batch);
+    const size_t xs = (size_t)2 * VK_WN_CK * (TN + 64), as = (size_t)a->hidden * (TN + 4);
+    const size_t lds = (xs > as ? xs : as) * sizeof(float);
+    int e = vk_launch_wn_layer(b_rep, a->last ? 1 : 0, vec, q, grid, lds, (hipStream_t)stream);
+    if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_wn_layer: this combination is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
     return VK_OK;
 }

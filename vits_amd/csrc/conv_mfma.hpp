@@ -38,7 +38,20 @@ struct ConvDev {
                         // 4 = stage only the first chunk, 8 = barrier only on the first chunk
 };
 
-__device__ __forceinline__ float vk_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+// tanh(a) * sigmoid(b) on the hardware exp2 / reciprocal units (each about 1 ulp): ten vector
+// instructions instead of the several dozen of the library tanhf / expf / division, which matter
+// because every one of them waits behind the other waves' fp32 matrix instructions.
+//   sigmoid(b) = 1 / (1 + 2^(-b log2 e)),   tanh(a) = 1 - 2 / (1 + 2^(2 a log2 e))
+// Saturation is exact (2^x -> inf or 0 gives 0, 1 or -1); the absolute error is about 2e-7.
+__device__ __forceinline__ float vk_gate(float a, float b)
+{
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float eb = __builtin_amdgcn_exp2f(-LOG2E * b);
+    const float ea = __builtin_amdgcn_exp2f(2.0f * LOG2E * a);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + eb);
+    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + ea);
+    return th * sg;
+}
 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -240,7 +253,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& d, f32x16 (&acc)[A_
                         const float vb = acc[m + 1][n][r];
                         float* op = p.out + ob + (int64_t)rr * p.out_cstride;
                         if constexpr (EPI == VK_EPI_GATE) {
-                            op[loff] = tanhf(va) * vk_sigmoid(vb);
+                            op[loff] = vk_gate(va, vb);
                         } else {
                             const float mean = va * mkv, logs = vb * mkv;
                             op[loff] = mean;
@@ -364,7 +377,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& d, f32x16 (&acc)[A_
                     const float vb = acc[m + 1][n][r];
                     const int64_t o = ob + (int64_t)row * p.out_cstride + t;
                     if constexpr (EPI == VK_EPI_GATE) {
-                        p.out[o] = tanhf(va) * vk_sigmoid(vb);
+                        p.out[o] = vk_gate(va, vb);
                     } else {   // VK_EPI_SAMPLE: out = mean, out3 = log-std, out2 = sampled latent
                         const float mean = va * mk[n];
                         const float logs = vb * mk[n];

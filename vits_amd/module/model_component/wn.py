@@ -7,9 +7,10 @@ speaker_id_embedded)`` and the same ``state_dict`` keys (``in_resblocks.{i}``,
 
 Per layer the reference runs a k-tap conv (H -> 2H), adds the layer's slice of the speaker
 conditioning, gates tanh*sigmoid, runs a 1x1 conv (H -> 2H, last layer H) and splits the
-result into a masked residual update and a skip accumulation.  Here that is two launches
-of the fp32-MFMA convolution kernel: conv + conditioning bias + gate in one epilogue, and
-1x1 conv + residual/skip/mask in the other.  The conditioning 1x1 conv on the [B, G, 1]
+result into a masked residual update and a skip accumulation.  For hidden = 192 in fp32 that
+is one launch per layer (csrc/wn_layer.hpp: the gated activations stay in LDS between the two
+convolutions).  Otherwise it is two launches of the convolution kernel: conv + conditioning
+bias + gate in one epilogue, and 1x1 conv + residual/skip/mask in the other.  The conditioning 1x1 conv on the [B, G, 1]
 speaker vector is one wavefront-reduced GEMV for all layers, with the in-conv biases
 folded in.
 """
@@ -18,19 +19,29 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ... import native
-from ...engine import PackedConv, PlanCache, WeightNormConvParams, require_device
+import os
+
+from ... import native, packing
+from ...engine import PackedConv, PlanCache, WeightNormConvParams, precision, require_device
 from ...packing import pair_row_order
 
 
 class WNPlan:
     """Packed weights of one WN stack on one device."""
 
+    fused_max_columns = 16384
+
     def __init__(self, wn: "WN", device):
         H, n = wn.hidden_channels, wn.n_resblocks
         order = pair_row_order(H).to(device)
         self.hidden, self.n_layers = H, n
         self.in_convs, self.rs_convs = [], []
+        # one launch per layer where the fused kernel exists (VITS_AMD_WN_FUSION=0 disables it)
+        wi = native.wn_info(H) if (precision() == native.PREC_F32
+                                   and os.environ.get("VITS_AMD_WN_FUSION", "1") != "0") else None
+        k = wn.kernel_size
+        self.fused = wi is not None and all((k - 1) * wn.dilation_rate ** i <= 56 for i in range(n))
+        self.fused_w = []
         cond_bias = wn.condition_layer.bias.detach().to(device).clone()
         for i in range(n):
             m = wn.in_resblocks[i]
@@ -40,6 +51,10 @@ class WNPlan:
             cond_bias[2 * H * i:2 * H * (i + 1)] += m.bias.detach().to(device)
             r = wn.res_skip_layers[i]
             self.rs_convs.append(PackedConv(r.effective_weight(), r.bias, device))
+            if self.fused:
+                self.fused_w.append((
+                    packing.pack_conv_weight(m.effective_weight().to(device), wi.ck, wi.rows_per_block, order),
+                    packing.pack_conv_weight(r.effective_weight().to(device), wi.ck, 32)))
         # conditioning GEMV: rows = 2H * n, in-conv biases folded into its bias
         self.cond_w = wn.condition_layer.effective_weight().to(device)[:, :, 0].contiguous()
         self.cond_b = cond_bias.contiguous()
@@ -55,11 +70,27 @@ class WNPlan:
         """x [B,H,T] is consumed (updated in place); mask2 [B,T]; cond [B, *] holds this
         stack's gate biases starting at column ``cond_offset``.  Returns the masked skip sum."""
         B, H, T = x.shape
-        acts = torch.empty_like(x)
         skip = torch.empty_like(x)
         if out is None:
             out = torch.empty_like(x)
         cstride = cond.stride(0)
+        # Measured on the MI355X: the one-launch layer wins for small batches (fewer dependent
+        # launches: 6.85 -> 6.57 ms for one 10 s utterance), ties at 16 x 862 frames, and loses to
+        # the two-launch form beyond that (its 6-wave workgroups fill the SIMDs less evenly).
+        if self.fused and B * T <= self.fused_max_columns:
+            other = torch.empty_like(x)             # layers ping-pong: a layer's output may not land on its input
+            for i in range(self.n_layers):
+                ic, rc = self.in_convs[i], self.rs_convs[i]
+                w_in, w_rs = self.fused_w[i]
+                last = i == self.n_layers - 1
+                dst = out if last else other
+                if last and out.data_ptr() == x.data_ptr():
+                    raise native.NativeError("WN: the output buffer aliases the last layer's input")
+                native.wn_layer(x, w_in, cond[:, cond_offset + 2 * H * i:], cstride, w_rs, rc.bias, dst, skip, mask2,
+                                taps=ic.taps, dilation=ic.dilation, first=(i == 0), last=last)
+                x, other = dst, x
+            return out
+        acts = torch.empty_like(x)
         for i in range(self.n_layers):
             ic, rc = self.in_convs[i], self.rs_convs[i]
             bias_view = cond[:, cond_offset + 2 * H * i:]

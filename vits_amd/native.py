@@ -61,6 +61,21 @@ class PairArgs(C.Structure):
     ]
 
 
+class WnArgs(C.Structure):
+    """Mirror of ``vk_wn_args``."""
+    _fields_ = [
+        ("x", _fp), ("x_bstride", C.c_int64), ("x_cstride", C.c_int64),
+        ("w_in", _fp),
+        ("cond", _fp), ("cond_bstride", C.c_int64),
+        ("w_rs", _fp), ("bias_rs", _fp),
+        ("x_out", _fp), ("xo_bstride", C.c_int64), ("xo_cstride", C.c_int64),
+        ("skip", _fp), ("skip_bstride", C.c_int64), ("skip_cstride", C.c_int64),
+        ("mask", _fp),
+        ("batch", C.c_int32), ("hidden", C.c_int32), ("length", C.c_int32), ("taps", C.c_int32),
+        ("dilation", C.c_int32), ("first", C.c_int32), ("last", C.c_int32),
+    ]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -87,6 +102,8 @@ def lib():
                                         C.c_float, C.c_void_p]
         L.vk_pair_query.argtypes = [C.c_int, C.c_int, C.POINTER(TileInfo)]
         L.vk_resblock_pair.argtypes = [C.POINTER(PairArgs), C.c_void_p]
+        L.vk_wn_query.argtypes = [C.c_int, C.POINTER(TileInfo)]
+        L.vk_wn_layer.argtypes = [C.POINTER(WnArgs), C.c_void_p]
         if L.vk_abi_version() != 2:
             raise NativeError("libvits_amd.so ABI version mismatch")
         _lib = L
@@ -265,6 +282,39 @@ def resblock_pair(x, w1, bias1, w2, bias2, out, *, taps, dilation, epilogue, slo
     nbytes = 4.0 * (x.numel() + out.numel() + (acc.numel() if acc is not None else 0))
     check(_timed(family, flops, nbytes, x.device, lambda: L.vk_resblock_pair(C.byref(a), sp), detail),
           "vk_resblock_pair")
+
+
+_wn_cache = {}
+
+
+def wn_info(hidden: int):
+    """Packing geometry of the fused WN layer kernel for this width, or None if there is none."""
+    if hidden not in _wn_cache:
+        ti = TileInfo()
+        _wn_cache[hidden] = ti if lib().vk_wn_query(hidden, C.byref(ti)) == 0 else None
+    return _wn_cache[hidden]
+
+
+def wn_layer(x, w_in, cond, cond_bstride, w_rs, bias_rs, x_out, skip, mask, *, taps, dilation, first, last):
+    """One WN layer: gate conv + conditioning + tanh*sigmoid + 1x1 res/skip conv + residual, skip
+    and mask updates in one launch.  ``x_out`` (the output on the last layer) must not alias ``x``."""
+    assert x.is_cuda and mask.dtype == torch.float32 and mask.is_contiguous()
+    a = WnArgs()
+    a.x, a.x_bstride, a.x_cstride = _view(x)
+    a.w_in, a.w_rs = w_in.data_ptr(), w_rs.data_ptr()
+    a.cond, a.cond_bstride = cond.data_ptr(), cond_bstride
+    a.bias_rs = bias_rs.data_ptr() if bias_rs is not None else None
+    a.x_out, a.xo_bstride, a.xo_cstride = _view(x_out)
+    a.skip, a.skip_bstride, a.skip_cstride = _view(skip)
+    a.mask = mask.data_ptr()
+    a.batch, a.hidden, a.length = x.shape
+    a.taps, a.dilation, a.first, a.last = taps, dilation, int(first), int(last)
+    B, H, T = x.shape
+    flops = 2.0 * B * T * H * (2 * H * taps + (H if last else 2 * H))
+    nbytes = 4.0 * B * H * T * (3 if last else 5)
+    L, sp = lib(), stream_ptr(x.device)
+    check(_timed(f"wn_layer[{'last' if last else 'mid'}]", flops, nbytes, x.device,
+                 lambda: L.vk_wn_layer(C.byref(a), sp), f"B{B} L{T} h{H} k{taps} d{dilation}"), "vk_wn_layer")
 
 
 def speaker_linear(g, w, bias, out):
