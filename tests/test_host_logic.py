@@ -150,3 +150,10 @@ def test_cpu_tensors_fail_loudly():
     dec = Decoder(speaker_id_embedding_dim=256)
     with pytest.raises(native.NativeError):
         dec(torch.zeros(1, 192, 4), torch.zeros(1, 256, 1))
+
+
+def test_graft_entry_build_accepts_the_current_library():
+    """The driver's build check: compiles nothing new when up to date, loads the library and
+    agrees with the header's ABI version."""
+    import __graft_entry__ as entry
+    entry.build()
