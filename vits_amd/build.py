@@ -48,6 +48,10 @@ def build(force: bool = False, jobs: int | None = None) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = _sources()
     hdr_mtime = _headers_mtime()
+    # a library newer than every source is up to date even where the object files did not travel
+    newest = max([hdr_mtime] + [os.path.getmtime(os.path.join(CSRC, f)) for f in srcs])
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) > newest:
+        return LIB
     jobs = jobs or min(8, len(srcs))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, hdr_mtime), srcs))
