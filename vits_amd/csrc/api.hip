@@ -136,7 +136,18 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     d->stamps = g_stamps;
     const int rows_blk = 32 * G.a_rep * G.wm;
     const int64_t rows = gemm_rows(a);
-    *grid = dim3((unsigned)((a->length + TN - 1) / TN), (unsigned)((rows + rows_blk - 1) / rows_blk), (unsigned)a->batch);
+    d->n_tiles = (a->length + TN - 1) / TN;
+    d->n_rowblk = (int)((rows + rows_blk - 1) / rows_blk);
+    // Placing the row blocks of a time tile on one XCD cuts the fetched bytes of the multi-row-block
+    // launches by 2-4x (one HBM read of the x tile per XCD instead of one per row block).  It pays where
+    // the kernel is HBM-bound (bf16 inputs); the fp32 kernels are MFMA-bound and run 0.4 % slower with it.
+    // VK_XCD_MAP=0 / 1 forces it off / on for every precision.
+    static const int xcd_env = getenv("VK_XCD_MAP") ? atoi(getenv("VK_XCD_MAP")) : -1;
+    d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : a->precision == VK_PREC_BF16);
+    if (d->xcd_map)
+        *grid = dim3((unsigned)(8 * ((d->n_tiles + 7) / 8) * d->n_rowblk), 1, (unsigned)a->batch);
+    else
+        *grid = dim3((unsigned)d->n_tiles, (unsigned)d->n_rowblk, (unsigned)a->batch);
     *lds = bf16 ? (size_t)2 * (TN + 64) * ((split ? 3 : 1) * ck * 2 + 16) : (size_t)2 * G.ck * d->lds_stride * sizeof(float);
     static const int lds_min = getenv("VK_LDS_MIN") ? atoi(getenv("VK_LDS_MIN")) : 0;   // occupancy experiments
     if ((int)*lds < lds_min) *lds = lds_min;

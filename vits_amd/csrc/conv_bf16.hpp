@@ -156,8 +156,15 @@ conv_bf16_kernel(const ConvDev d)
     const int half = lane >> 5;
     const int l31  = lane & 31;
     const int b    = blockIdx.z;
-    const int t0   = blockIdx.x * TN;
-    const int mt0  = (blockIdx.y * WM + wm) * A_REP;
+    int tile = blockIdx.x, rowblk = blockIdx.y;
+    if (d.xcd_map) {                                   // see conv_mfma_kernel: row blocks of a time tile share an XCD
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        rowblk = slot % d.n_rowblk;
+        tile = (slot / d.n_rowblk) * 8 + xcd;
+        if (tile >= d.n_tiles) return;
+    }
+    const int t0   = tile * TN;
+    const int mt0  = (rowblk * WM + wm) * A_REP;
     const int L    = p.length;
 
     const float* xb = p.x + (int64_t)b * p.x_bstride;

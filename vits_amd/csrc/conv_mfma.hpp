@@ -34,6 +34,11 @@ struct ConvDev {
     int col0;           // staged column of time t0 - pad (vector staging starts at a multiple of 4 columns)
     unsigned x_bytes, out_bytes, res_bytes, out2_bytes;   // byte spans of one batch item's views (buffer bounds)
     unsigned long long* stamps;   // diagnostic: 8 x u64 per workgroup (times, placement) or null
+    int n_tiles;        // time tiles per batch item
+    int n_rowblk;       // row blocks; > 1 with xcd_map: blockIdx.x enumerates (XCD, row block, tile group)
+    int xcd_map;        // 1: workgroups that share a staged x tile (all row blocks of a time tile) are
+                        // placed on the same XCD in consecutive dispatch slots, so the tile is fetched
+                        // from HBM once per XCD instead of once per row block
     int dbg;            // timing experiments only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop,
                         // 4 = stage only the first chunk, 8 = barrier only on the first chunk
 };
@@ -480,8 +485,16 @@ conv_mfma_kernel(const ConvDev d)
     const int half = lane >> 5;
     const int l31  = lane & 31;
     const int b    = blockIdx.z;
-    const int t0   = blockIdx.x * TN;
-    const int mt0  = (blockIdx.y * WM + wm) * A_REP;   // first packed 32-row tile of this wave
+    int tile = blockIdx.x, rowblk = blockIdx.y;
+    if (d.xcd_map) {
+        // hardware deals consecutive workgroup ids round-robin over the 8 XCDs
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        rowblk = slot % d.n_rowblk;
+        tile = (slot / d.n_rowblk) * 8 + xcd;
+        if (tile >= d.n_tiles) return;                 // padding of the last tile group (whole workgroup leaves)
+    }
+    const int t0   = tile * TN;
+    const int mt0  = (rowblk * WM + wm) * A_REP;       // first packed 32-row tile of this wave
     const int L    = p.length;
     constexpr int STRIDE = TN + 64;          // floats between staged rows (the host checks that tile + halo fits)
 
