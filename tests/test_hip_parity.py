@@ -232,3 +232,43 @@ def test_front_half_graph_replay_matches_eager():
         assert torch.equal(a, b)
     finally:
         gen.use_front_graph = False
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (2, 5)])
+def test_tiny_sequences_end_to_end(sd, B, T):
+    """One to five latent frames: every staged tile is mostly halo, the fused and concurrent
+    small-batch paths are all active."""
+    gen = HotPathGenerator(100)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    lens = [max(1, T - i) for i in range(B)]
+    mask = synth.length_mask(lens, T)
+    z_p = synth.latent(SEED, f"tiny.z{B}x{T}", B, T) * mask
+    ids = torch.arange(B) * 7 % 100
+    g = O.speaker_embed(ids, sd)
+    ref = O.flow_reverse_decode(z_p, mask, g, sd)
+    wav = gen.flow_reverse_decode(z_p.to(DEV), mask.to(DEV), gen.embed_speaker(ids.to(DEV)))
+    err = _check(wav, ref, what=f"hot path B={B} T={T}")
+    assert err <= CONTRACT and wav.shape == (B, 1, 256 * T)
+    spec = synth.power_spectrogram(SEED, f"tiny.spec{B}x{T}", B, T)
+    eps = synth.latent(SEED, f"tiny.eps{B}x{T}", B, T)
+    lt = torch.tensor(lens)
+    tgt = (ids + 13) % 100
+    want = O.voice_conversion(spec, lt, ids, tgt, sd, eps)
+    got = gen.voice_conversion(spec.to(DEV), lt.to(DEV), ids.to(DEV), tgt.to(DEV), noise=eps.to(DEV))
+    assert _check(got, want, what=f"voice conversion B={B} T={T}") <= CONTRACT
+
+
+def test_long_batch_of_ragged_utterances(sd):
+    """The longest corpus utterances (15 s = 1292 frames) in a ragged batch of 4: full tiles,
+    edge tiles and masked tails together; checked on strided samples against the oracle."""
+    gen = HotPathGenerator(100)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    T, lens = 1292, [1292, 1001, 640, 173]
+    mask = synth.length_mask(lens, T)
+    z_p = synth.latent(SEED, "long.z", 4, T) * mask
+    ids = torch.tensor([1, 22, 63, 94])
+    wav = gen.flow_reverse_decode(z_p.to(DEV), mask.to(DEV), gen.embed_speaker(ids.to(DEV))).cpu()
+    ref = O.flow_reverse_decode(z_p, mask, O.speaker_embed(ids, sd), sd)
+    assert _check(wav, ref, what="long ragged batch") <= CONTRACT
