@@ -9,7 +9,8 @@
 // staging; every tap of the convolution then reads it at a shifted column, so nothing is
 // re-fetched from HBM per tap and no im2col matrix exists.  Weights arrive pre-packed in
 // fragment order (see packing.py) and stream straight from L2 into registers, one 16-byte
-// load per lane per four k-steps, prefetched one group ahead.
+// load per lane per four k-steps; a group's registers are refilled for the next tap right
+// after their last use.
 //
 // Matrix instruction: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  Operand maps:
 //   A: lane l holds A[row = l & 31][k = l >> 5]        (k = channel within the pair)
@@ -518,9 +519,9 @@ conv_mfma_kernel(const ConvDev d)
     for (int m = 0; m < A_REP; ++m)
         aptr[m] = reinterpret_cast<const float4*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
 
-    // Weight fragments are fetched one whole tap (GPC groups) ahead: the loads for tap+1 are
-    // issued when tap starts and first touched when it ends, so a full tap of MFMAs covers
-    // them, and the in-order memory counter gives the chunk's staging loads the same cover.
+    // Weight fragments of a tap live in GPC register groups; in the tap loop each group is
+    // reloaded for the next tap as soon as its four k-steps have been issued, so the other
+    // groups' MFMAs cover the L2 latency and no register is copied at the loop's back edge.
     float4 a[GPC][A_REP];
 #pragma unroll
     for (int g = 0; g < GPC; ++g)
