@@ -333,7 +333,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& d, f32x16 (&acc)[A_
                         const int so = rr * (int)p.out_cstride * 4;
                         const int voo = vo + 128 * n;
                         if constexpr (EPI == VK_EPI_STORE) {
-                            vk_bst(v * mkv, r_out, voo, so);
+                            if (maskb) vk_bst(v * mkv, r_out, voo, so);      // wave-uniform: the decoder has no mask
+                            else       vk_bst(v, r_out, voo, so);
                         } else if constexpr (EPI == VK_EPI_RESID) {
                             vk_bst(v + rv[r], r_out, voo, so);
                         } else if constexpr (EPI == VK_EPI_RESID_ACC) {
