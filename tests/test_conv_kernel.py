@@ -451,3 +451,24 @@ def test_fused_wn_layer(B, T, lens, dil):
     with pytest.raises(native.NativeError):          # output on top of the input
         native.wn_layer(xd, p_in, cond.to(DEV), 2 * H, p_rs, b_rs.to(DEV), xd, skip, md,
                         taps=k, dilation=dil, first=True, last=False)
+
+
+def test_split_conv_over_a_wide_dynamic_range():
+    """Slices keep fp32's exponent range: channels scaled from 1e-18 to 1e+18 (weights scaled
+    inversely so the products stay O(1)) give the same relative accuracy as unit-scale data."""
+    cin, cout, k, B, L = 64, 64, 3, 2, 300
+    scale = torch.logspace(-18, 18, cin).view(1, cin, 1)
+    x = _rand(B, cin, L, seed=131) * scale
+    w = _rand(cout, cin, k, seed=132) / (cin * k) ** 0.5 / scale.view(1, cin, 1)
+    ref = F.conv1d(x.double(), w.double(), None, padding=1)
+    tile = choose_tile(cout)
+    out = torch.full((B, cout, L), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), _pack_split(w, tile), out, c_in=cin, c_out=cout, taps=k, dilation=1, pad=1, tile=tile,
+                  epilogue=native.EPI_STORE)
+    out32 = torch.full((B, cout, L), float("nan"), device=DEV)
+    native.conv1d(x.to(DEV), _pack(w, tile), out32, c_in=cin, c_out=cout, taps=k, dilation=1, pad=1, tile=tile,
+                  epilogue=native.EPI_STORE)
+    err = (out.cpu().double() - ref).abs().max().item()
+    err32 = (out32.cpu().double() - ref).abs().max().item()
+    print(f"wide range: split {err:.2e}, fp32 MFMA {err32:.2e}, |ref|max {ref.abs().max().item():.2f}")
+    assert err <= max(2.0 * err32, 1e-6)
