@@ -42,8 +42,8 @@ extern "C" int vk_speaker_linear(const float* g, const float* w, const float* bi
 
 // Output convolution: C channels -> 1, `taps` wide, leaky-ReLU on the input, tanh on the
 // output.  A workgroup produces 1024 consecutive samples; channels are staged through LDS
-// eight at a time (with the activation applied once per element) and each thread keeps
-// four adjacent outputs in registers.
+// eight at a time (with the activation applied once per element; the next eight are already
+// being loaded) and each thread keeps four outputs in registers.
 constexpr int POST_TILE = 1024;
 constexpr int POST_CH   = 8;
 constexpr int POST_MAXTAPS = 16;
@@ -54,28 +54,45 @@ post_conv_tanh_kernel(const float* __restrict__ x, const float* __restrict__ w,
 {
     __shared__ float tile[POST_CH][POST_TILE + POST_MAXTAPS];
     __shared__ float wl[POST_CH][POST_MAXTAPS];
+    constexpr int NCOL = (POST_TILE + POST_MAXTAPS + 255) / 256;     // staged columns per thread per row
     const int b  = blockIdx.y;
     const int t0 = blockIdx.x * POST_TILE;
     const int pad = (taps - 1) / 2;
     const int width = POST_TILE + taps - 1;
     const float* xb = x + (int64_t)b * channels * length;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c0 = 0; c0 < channels; c0 += POST_CH) {
-        __syncthreads();
+    // the next chunk's loads are in flight while the current chunk is consumed
+    float st[POST_CH][NCOL];
+    auto issue = [&](int c0) {
+#pragma unroll
         for (int c = 0; c < POST_CH; ++c) {
             const bool cok = (c0 + c) < channels;
             const float* row = xb + (int64_t)(cok ? c0 + c : 0) * length;
-            for (int col = threadIdx.x; col < width; col += 256) {
+#pragma unroll
+            for (int i = 0; i < NCOL; ++i) {
+                const int col = threadIdx.x + 256 * i;
                 const int t = t0 - pad + col;
-                float v = (cok && t >= 0 && t < length) ? row[t] : 0.0f;
-                tile[c][col] = v > 0.0f ? v : v * slope;
+                st[c][i] = (cok && col < width && t >= 0 && t < length) ? row[t] : 0.0f;
             }
         }
+    };
+    issue(0);
+    for (int c0 = 0; c0 < channels; c0 += POST_CH) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < POST_CH; ++c)
+#pragma unroll
+            for (int i = 0; i < NCOL; ++i) {
+                const int col = threadIdx.x + 256 * i;
+                const float v = st[c][i];
+                if (col < POST_TILE + POST_MAXTAPS) tile[c][col] = v > 0.0f ? v : v * slope;
+            }
         if (threadIdx.x < POST_CH * POST_MAXTAPS) {
             const int c = threadIdx.x / POST_MAXTAPS, j = threadIdx.x % POST_MAXTAPS;
             wl[c][j] = ((c0 + c) < channels && j < taps) ? w[(c0 + c) * taps + j] : 0.0f;
         }
         __syncthreads();
+        if (c0 + POST_CH < channels) issue(c0 + POST_CH);
         for (int c = 0; c < POST_CH; ++c) {
             for (int j = 0; j < taps; ++j) {
                 const float wv = wl[c][j];
