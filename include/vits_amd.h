@@ -86,7 +86,8 @@ typedef struct {
 #define VK_EPI_WN_LAST    6 /* out2 = (out2 + v) * mask                wn.py:85-86                 */
 #define VK_EPI_COUPLE_REV 7 /* out = (out - v*mask) * mask             flow.py:58,67               */
 #define VK_EPI_COUPLE_FWD 8 /* out = v*mask + out*mask                 flow.py:58,63               */
-#define VK_EPI_UPSAMPLE   9 /* polyphase ConvTranspose1d scatter store decoder.py:117              */
+#define VK_EPI_UPSAMPLE   9 /* polyphase ConvTranspose1d scatter store decoder.py:117  (rows: phase*c_out + channel;
+                               stride 8: tile = 8 channels x 4 phases, see packing.polyphase_row_order) */
 #define VK_EPI_SAMPLE    10 /* (m,logs) pairs: m, logs, z=(m+eps*exp(logs))*mask  posterior_encoder.py:56-59 */
 #define VK_EPI_COUNT     11
 

@@ -90,7 +90,7 @@ def test_polyphase_upsample(cin, cout, s, B, L):
     poly = packing.transposed_to_polyphase(wt, s)
     tile = choose_tile(poly.shape[0])
     out = torch.full((B, cout, L * s), float("nan"), device=DEV)
-    native.conv1d(x.to(DEV), _pack(poly, tile), out, c_in=cin, c_out=cout, taps=2, dilation=1, pad=1, tile=tile,
+    native.conv1d(x.to(DEV), _pack(poly, tile, packing.polyphase_row_order(cout, s)), out, c_in=cin, c_out=cout, taps=2, dilation=1, pad=1, tile=tile,
                   epilogue=native.EPI_UPSAMPLE, bias=bias.to(DEV), act_in=True, in_slope=0.1, up_stride=s)
     _close(out, ref, "upsample")
 
@@ -292,7 +292,7 @@ def test_bf16_polyphase_upsample(cin, cout, s, B, L):
     poly = packing.transposed_to_polyphase(wt, s)
     tile = choose_tile(poly.shape[0])
     out = torch.full((B, cout, L * s), float("nan"), device=DEV)
-    native.conv1d(x.to(DEV), _pack16(poly, tile), out, c_in=cin, c_out=cout, taps=2, dilation=1, pad=1, tile=tile,
+    native.conv1d(x.to(DEV), _pack16(poly, tile, packing.polyphase_row_order(cout, s)), out, c_in=cin, c_out=cout, taps=2, dilation=1, pad=1, tile=tile,
                   epilogue=native.EPI_UPSAMPLE, bias=bias.to(DEV), act_in=True, in_slope=0.1, up_stride=s)
     _close(out, ref, "bf16 upsample")
 

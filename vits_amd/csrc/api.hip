@@ -86,7 +86,10 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     case VK_EPI_UPSAMPLE:
         if (a->up_stride < 2 || (a->up_stride & 1) || a->taps != 2 || a->dilation != 1 || a->pad != 1)
             return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: upsample needs even stride, 2 polyphase taps, pad 1");
-        if (a->c_out % (32 * G.a_rep))
+        if (a->up_stride == 8) {        // grouped row layout, 16-byte stores
+            if (a->c_out % 8 || ((uintptr_t)a->out % 16) || (a->out_bstride % 4) || (a->out_cstride % 4))
+                return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: stride-8 upsample needs c_out % 8 == 0 and a 16-byte aligned output view");
+        } else if (a->c_out % (32 * G.a_rep))
             return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: upsample needs c_out to be a multiple of the wave's row span");
         break;
     default: break;

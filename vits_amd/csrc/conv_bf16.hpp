@@ -183,24 +183,31 @@ conv_bf16_kernel(const ConvDev d)
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) a[k][m] = aptr[m][64 * k];
 
-    // accumulators start at the bias of their row
     f32x16 acc[A_REP][B_REP];
     {
+        // accumulators start at the bias of their row: register r of a lane is row
+        // (r & 3) + 8 * (r >> 2) + 4 * half of its 32-row tile
         const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
-        const int rows_total_b = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
+        const int rows_total_b = PAIR ? 2 * p.hidden : p.c_out;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) {
             float bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int prow = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                int brow = prow;
-                if (PAIR) brow = ((m & 1) ? p.hidden : 0) + 32 * ((mt0 + m) >> 1) + (prow & 31);
-                if (EPI == VK_EPI_UPSAMPLE) brow = prow % p.c_out;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int prow = (mt0 + m) * 32 + i;                                     // packed row
+                int brow = prow;                                                         // bias index
+                bool ok = prow < rows_total_b;
+                if (PAIR) brow = ((m & 1) ? p.hidden : 0) + 32 * ((mt0 + m) >> 1) + i;
+                if (EPI == VK_EPI_UPSAMPLE) {
+                    int phase;
+                    vk_ups_row(p, mt0 + m, i, brow, phase);
+                    ok = brow < p.c_out && phase < p.up_stride;
+                }
                 bv[r] = 0.0f;
-                if (biasb != nullptr) {
-                    const float raw = biasb[prow < rows_total_b ? brow : 0];
-                    bv[r] = prow < rows_total_b ? raw : 0.0f;
+                if (biasb != nullptr) {                      // wave-uniform
+                    const float raw = biasb[ok ? brow : 0];
+                    bv[r] = ok ? raw : 0.0f;
                 }
             }
 #pragma unroll
@@ -209,12 +216,7 @@ conv_bf16_kernel(const ConvDev d)
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = bv[r];
         }
     }
-
-    int shift = 0;          // transposed conv: upper phases read one column later
-    if (EPI == VK_EPI_UPSAMPLE) {
-        const int phase = (mt0 * 32) / p.c_out;
-        shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
-    }
+    const int shift = (EPI == VK_EPI_UPSAMPLE) ? vk_ups_shift(p, mt0) : 0;     // upper phases read one column later
     const int bcol = (wn * TNW + l31 + shift) * PITCH + half * 16;
     const int tap_step = p.dilation * PITCH;
 

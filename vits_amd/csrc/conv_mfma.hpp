@@ -212,6 +212,32 @@ __device__ __forceinline__ void vk_stamp(const ConvDev& d, int slot)
     }
 }
 
+// Row layout of the polyphase transposed convolution (VK_EPI_UPSAMPLE).
+//  - stride 8 ("grouped"): a 32-row tile holds 8 channels x 4 phases of one half of the phases,
+//    tile mt = (channel group mt >> 1, half mt & 1), row-in-tile i = 4 * channel + phase-in-half.
+//    A lane's four consecutive registers are then four consecutive output samples of one channel
+//    (one 16-byte store), and a whole tile shares the staged-column shift of its half.
+//  - other strides: packed row = phase * c_out + channel (a tile is 32 channels of one phase).
+__device__ __forceinline__ bool vk_ups_grouped(const vk_conv_args& p) { return p.up_stride == 8; }
+__device__ __forceinline__ void vk_ups_row(const vk_conv_args& p, int mt, int i, int& co, int& phase)
+{
+    if (vk_ups_grouped(p)) {
+        co = 8 * (mt >> 1) + (i >> 2);
+        phase = 4 * (mt & 1) + (i & 3);
+    } else {
+        const int prow = mt * 32 + i;
+        phase = prow / p.c_out;
+        co = prow - phase * p.c_out;
+    }
+}
+// upper phases read the staged tile one column later
+__device__ __forceinline__ int vk_ups_shift(const vk_conv_args& p, int mt)
+{
+    int co, phase;
+    vk_ups_row(p, mt, 0, co, phase);
+    return phase >= (p.up_stride >> 1) ? 1 : 0;
+}
+
 // Fused epilogue of one wave's accumulators (A_REP x B_REP tiles of 32 x 32, rows starting at
 // packed tile mt0, columns at t0 + wn * 32 * B_REP); shared by every main-loop variant.
 template <int A_REP, int B_REP, int EPI>
@@ -273,18 +299,41 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& d, f32x16 (&acc)[A_
         } else if constexpr (EPI == VK_EPI_UPSAMPLE) {
             const int S = p.up_stride;
             const __amdgpu_buffer_rsrc_t r_out = vk_rsrc(p.out + ob, d.out_bytes);
+            if (vk_ups_grouped(p)) {
+                // registers 4j..4j+3 of a lane: channel 8*cg + 2j + half, output samples 8t + 4*half_of_phases + 0..3
 #pragma unroll
-            for (int m = 0; m < A_REP; ++m) {
-                const int prow0 = (mt0 + m) * 32;
-                const int phase = prow0 / p.c_out;
-                const int co0 = prow0 - phase * p.c_out;
-                const int vo = 4 * (4 * half * (int)p.out_cstride + tw * S + phase);
+                for (int m = 0; m < A_REP; ++m) {
+                    const int cg = (mt0 + m) >> 1, cls = (mt0 + m) & 1;
+                    const int vo = 4 * (half * (int)p.out_cstride + tw * 8 + 4 * cls);
 #pragma unroll
-                for (int n = 0; n < B_REP; ++n) {
-                    const int von = vo + 128 * n * S;
+                    for (int n = 0; n < B_REP; ++n) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        vk_bst(acc[m][n][r], r_out, von, (co0 + (r & 3) + 8 * (r >> 2)) * (int)p.out_cstride * 4);
+                        for (int j = 0; j < 4; ++j) {
+                            u32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float f = acc[m][n][4 * j + e];     // by value: bit_cast of a vector element lvalue reads element 0
+                                v[e] = __builtin_bit_cast(unsigned int, f);
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(v, r_out, vo + 128 * n * 8,
+                                                                   (8 * cg + 2 * j) * (int)p.out_cstride * 4, 0);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) {
+                    const int prow0 = (mt0 + m) * 32;
+                    const int phase = prow0 / p.c_out;
+                    const int co0 = prow0 - phase * p.c_out;
+                    const int vo = 4 * (4 * half * (int)p.out_cstride + tw * S + phase);
+#pragma unroll
+                    for (int n = 0; n < B_REP; ++n) {
+                        const int von = vo + 128 * n * S;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            vk_bst(acc[m][n][r], r_out, von, (co0 + (r & 3) + 8 * (r >> 2)) * (int)p.out_cstride * 4);
+                    }
                 }
             }
         } else {
@@ -399,13 +448,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& d, f32x16 (&acc)[A_
         const int S = p.up_stride;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) {
-            const int prow0 = (mt0 + m) * 32;
-            const int phase = prow0 / p.c_out;
-            if (phase >= S) continue;
-            const int co0 = prow0 - phase * p.c_out;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                int co, phase;
+                vk_ups_row(p, mt0 + m, (r & 3) + 8 * (r >> 2) + 4 * half, co, phase);
+                if (co >= p.c_out || phase >= S) continue;
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n) {
                     const int t = tw + 32 * n;
@@ -529,25 +576,31 @@ conv_mfma_kernel(const ConvDev d)
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) a[g][m] = aptr[m][64 * g];
 
-    // Accumulators start at the bias of their row (so no epilogue adds it): register r of this
-    // lane is row (r & 3) + 8 * (r >> 2) + 4 * half of the 32-row tile.
     f32x16 acc[A_REP][B_REP];
     {
+        // accumulators start at the bias of their row: register r of a lane is row
+        // (r & 3) + 8 * (r >> 2) + 4 * half of its 32-row tile
         const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
-        const int rows_total_b = PAIR ? 2 * p.hidden : (EPI == VK_EPI_UPSAMPLE ? p.c_out * p.up_stride : p.c_out);
+        const int rows_total_b = PAIR ? 2 * p.hidden : p.c_out;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) {
             float bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int prow = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // packed row
-                int brow = prow;                                                        // bias index
-                if (PAIR) brow = ((m & 1) ? p.hidden : 0) + 32 * ((mt0 + m) >> 1) + (prow & 31);
-                if (EPI == VK_EPI_UPSAMPLE) brow = prow % p.c_out;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int prow = (mt0 + m) * 32 + i;                                     // packed row
+                int brow = prow;                                                         // bias index
+                bool ok = prow < rows_total_b;
+                if (PAIR) brow = ((m & 1) ? p.hidden : 0) + 32 * ((mt0 + m) >> 1) + i;
+                if (EPI == VK_EPI_UPSAMPLE) {
+                    int phase;
+                    vk_ups_row(p, mt0 + m, i, brow, phase);
+                    ok = brow < p.c_out && phase < p.up_stride;
+                }
                 bv[r] = 0.0f;
                 if (biasb != nullptr) {                      // wave-uniform
-                    const float raw = biasb[prow < rows_total_b ? brow : 0];
-                    bv[r] = prow < rows_total_b ? raw : 0.0f;
+                    const float raw = biasb[ok ? brow : 0];
+                    bv[r] = ok ? raw : 0.0f;
                 }
             }
 #pragma unroll
@@ -558,11 +611,7 @@ conv_mfma_kernel(const ConvDev d)
     }
 
     // transposed conv: row tiles of the upper phases read the staged tile one column later
-    int shift = 0;
-    if (EPI == VK_EPI_UPSAMPLE) {
-        const int phase = (mt0 * 32) / p.c_out;
-        shift = (phase >= (p.up_stride >> 1)) ? 1 : 0;
-    }
+    const int shift = (EPI == VK_EPI_UPSAMPLE) ? vk_ups_shift(p, mt0) : 0;
     const int bcol = half * STRIDE + wn * TNW + l31 + shift + d.col0;
     
     unsigned long long boundary_ticks = 0;      // diagnostic: time spent handing over chunks 1..n-1

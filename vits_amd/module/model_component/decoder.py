@@ -150,7 +150,9 @@ class DecoderPlan:
             up = dec.ups[i]
             wt = up.effective_weight().to(device)
             poly = packing.transposed_to_polyphase(wt, s)
-            self.ups.append((PackedConv(poly, up.bias, device, pad=1), s, wt.shape[1]))
+            order = packing.polyphase_row_order(wt.shape[1], s)
+            self.ups.append((PackedConv(poly, up.bias, device, pad=1, row_order=None if order is None else order.to(device)),
+                             s, wt.shape[1]))
         self.resblocks = [rb.plan(device) for rb in dec.resblocks]
         self.side_streams = None            # created on first use by a small-batch forward
         self.post_w = dec.conv1d_post.weight.detach().to(device)[0].contiguous()    # [C, taps]

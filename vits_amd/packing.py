@@ -114,6 +114,22 @@ def pair_row_order(hidden: int) -> torch.Tensor:
     return torch.tensor(idx, dtype=torch.int64)
 
 
+def polyphase_row_order(c_out: int, stride: int):
+    """Packed-row order of the polyphase rows (phase * c_out + channel) the kernels expect, or None
+    for the natural order.  For stride 8 a 32-row tile holds 8 channels x the 4 phases of one half
+    of the phases (row-in-tile = 4 * channel + phase-in-half; tile = 2 * channel group + half), so
+    that a lane's four consecutive accumulator registers are four consecutive output samples."""
+    if stride != 8:
+        return None
+    assert c_out % 8 == 0
+    idx = []
+    for mt in range(c_out // 4):
+        cg, half = mt >> 1, mt & 1
+        for i in range(32):
+            idx.append((4 * half + (i & 3)) * c_out + 8 * cg + (i >> 2))
+    return torch.tensor(idx, dtype=torch.int64)
+
+
 def transposed_to_polyphase(wt: torch.Tensor, stride: int) -> torch.Tensor:
     """ConvTranspose1d weight [c_in, c_out, 2*stride] (padding stride/2) -> the weight of an
     equivalent 2-tap convolution with stride*c_out output rows, row = phase*c_out + channel.
