@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden
 vectors captured from the reference.  fp32 contract: max-abs 1e-4 on the waveform; the
-tighter gates below are what the fp32 MFMA path actually achieves."""
+tighter gates below are what the fp32 MFMA path actually achieves.  Every test runs twice:
+with the fp32 matrix instruction and with fp32 operands cut into exact bf16 slices
+("fp32-split"), against the same gates."""
 import os
 
 import numpy as np
@@ -20,6 +22,14 @@ SEED = 999
 DEV = "cuda:0"
 CONTRACT = 1e-4     # stated fp32 waveform tolerance
 GATE = 2e-5         # internal gate, relative to max(1, |ref|max)
+
+
+@pytest.fixture(autouse=True, params=["fp32", "fp32-split"])
+def precision_mode(request):
+    from vits_amd import engine
+    engine.set_precision(request.param)
+    yield request.param
+    engine.set_precision("fp32")
 
 
 def _gold(golden_dir, name):
@@ -275,3 +285,49 @@ def test_long_batch_of_ragged_utterances(sd):
     wav = gen.flow_reverse_decode(z_p.to(DEV), mask.to(DEV), gen.embed_speaker(ids.to(DEV))).cpu()
     ref = O.flow_reverse_decode(z_p, mask, O.speaker_embed(ids, sd), sd)
     assert _check(wav, ref, what="long ragged batch") <= CONTRACT
+
+
+def test_headline_shape_b16_t862(sd):
+    """The benchmarked step itself - 16 utterances x 862 frames, 16 speakers - with the first
+    and the last item checked against the CPU oracle (items are independent on this path, so
+    each goes through the oracle alone at the same padded length)."""
+    gen = HotPathGenerator(100)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    B, T = 16, 862
+    z_p = synth.latent(SEED, "bench.rank0", B, T)
+    mask = synth.length_mask([T] * B, T)
+    ids = synth.speaker_ids(SEED, "bench.rank0", B)
+    wav = gen.flow_reverse_decode(z_p.to(DEV), mask.to(DEV), gen.embed_speaker(ids.to(DEV)))
+    assert wav.shape == (B, 1, T * 256)
+    for i in (0, B - 1):
+        ref = O.flow_reverse_decode(z_p[i:i + 1], mask[i:i + 1], O.speaker_embed(ids[i:i + 1], sd), sd)
+        assert _check(wav[i:i + 1], ref, what=f"headline item {i}") <= CONTRACT
+
+
+def test_corpus_on_one_rank(sd):
+    """The sharded-corpus workload on a single rank: 64 utterances of 2-15 s, length-bucketed,
+    through the same shard -> run -> checksum code as bench.py; three utterances (longest
+    bucket, middle, shortest; the most padded item of each) against the CPU oracle."""
+    from vits_amd import sharding
+    gen = HotPathGenerator(100)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    frames, spk = sharding.synthetic_corpus(64, SEED)
+    work = sharding.shard_inputs(sharding.rank_shard(frames, spk, 1, 0), SEED, DEV)
+    assert sum(len(b.utterances) for b in work) == 64
+
+    def hot_path(z, mask, speakers):
+        return gen.flow_reverse_decode(z, mask, gen.embed_speaker(speakers))
+    kept = sharding.run_shard(work, hot_path, keep="all")
+    assert sorted(kept) == sorted(b.bucket_id for b in work)
+    for b in (work[0], work[len(work) // 2], work[-1]):
+        wav = kept[b.bucket_id]
+        assert wav.shape == (len(b.utterances), 1, 256 * int(b.lengths.max()))
+        i = len(b.utterances) - 1
+        ref = O.flow_reverse_decode(b.z[i:i + 1].cpu(), b.mask[i:i + 1].cpu(),
+                                    O.speaker_embed(b.speakers[i:i + 1].cpu(), sd), sd)
+        assert _check(wav[i:i + 1], ref, what=f"corpus bucket {b.bucket_id} item {i}") <= CONTRACT
+    row = sharding.metrics_row(1.0, work, checksum=sharding.valid_checksum(work, kept))
+    assert row[sharding.M_VALID_FRAMES] == frames.sum() and row[sharding.M_UTTERANCES] == 64
+    assert np.isfinite(row[sharding.M_CHECKSUM])

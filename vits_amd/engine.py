@@ -66,6 +66,10 @@ def precision() -> int:
     return _precision
 
 
+def precision_name() -> str:
+    return next(k for k, v in _PRECISIONS.items() if v == _precision)
+
+
 def choose_tile(rows: int) -> int:
     """Tile family for a GEMM with ``rows`` output rows: least row padding, then the
     largest rows-per-workgroup."""

@@ -66,3 +66,110 @@ def gather_metrics(values, device=None):
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return torch.stack(out).cpu()
+
+
+def rank_shard(frames, spk, world: int, rank: int, max_items: int = 16, frame_budget: int = 16 * 862):
+    """The buckets rank ``rank`` of ``world`` processes: a list of
+    (bucket id, utterance ids, lengths [n] int64, speaker ids [n] int64), heaviest first."""
+    buckets = make_buckets(frames, max_items, frame_budget)
+    parts, _ = assign_buckets(frames, buckets, world)
+    shard = []
+    for bi in parts[rank]:
+        idx = buckets[bi]
+        shard.append((bi, idx, torch.tensor([int(frames[i]) for i in idx], dtype=torch.int64),
+                      torch.tensor([int(spk[i]) for i in idx], dtype=torch.int64)))
+    return shard
+
+
+# columns of the per-rank metrics row every rank contributes after the timed region
+M_ELAPSED, M_VALID_FRAMES, M_PADDED_FRAMES, M_UTTERANCES, M_PARITY, M_CHECKSUM = range(6)
+METRIC_COLUMNS = 6
+
+
+def summarize(table, steps: int, hop: int = 256, sample_rate: int = 22050):
+    """Whole-job figures from the gathered [world, METRIC_COLUMNS] table: valid audio seconds of
+    all ranks over the slowest rank's time (the job is done when the last rank is)."""
+    t = torch.as_tensor(table, dtype=torch.float64)
+    elapsed = t[:, M_ELAPSED]
+    slowest = float(elapsed.max())
+    audio_s = float(t[:, M_VALID_FRAMES].sum()) * hop / sample_rate * steps
+    return {
+        "value": audio_s / slowest,
+        "ms_per_step": 1e3 * slowest / steps,
+        "ranks_seen": int(t.shape[0]),
+        "per_rank_ms_per_step": [1e3 * float(e) / steps for e in elapsed],
+        "per_rank_value": [float(f) * hop / sample_rate * steps / float(e)
+                           for f, e in zip(t[:, M_VALID_FRAMES], elapsed)],
+        "load_imbalance": slowest / float(elapsed.mean()),
+        "padding_overhead": float(t[:, M_PADDED_FRAMES].sum()) / max(float(t[:, M_VALID_FRAMES].sum()), 1.0),
+        "utterances_per_step": int(t[:, M_UTTERANCES].sum()),
+        "parity_max_abs": float(t[:, M_PARITY].max()),
+        "checksum": float(t[:, M_CHECKSUM].sum()),
+    }
+
+
+class Bucket:
+    """One padded batch of a rank's shard: utterance ids, lengths, latents, mask, speakers."""
+
+    __slots__ = ("bucket_id", "utterances", "lengths", "z", "mask", "speakers")
+
+    def __init__(self, bucket_id, utterances, lengths, z, mask, speakers):
+        self.bucket_id, self.utterances, self.lengths = bucket_id, utterances, lengths
+        self.z, self.mask, self.speakers = z, mask, speakers
+
+    @property
+    def valid_frames(self) -> int:
+        return int(self.lengths.sum())
+
+    @property
+    def padded_frames(self) -> int:
+        return int(self.lengths.numel() * self.lengths.max())
+
+
+def shard_inputs(shard, seed: int = 999, device=None):
+    """Synthetic masked latents for every bucket of a shard (the data a bucket holds depends
+    only on the seed and the bucket id, never on which rank processes it)."""
+    work = []
+    for bi, idx, lens, spk in shard:
+        tmax = int(lens.max())
+        m = synth.length_mask(lens, tmax)
+        z = synth.latent(seed, f"corpus.b{bi}", len(idx), tmax).mul_(m)
+        work.append(Bucket(bi, idx, lens, z.to(device), m.to(device), spk.to(device)))
+    return work
+
+
+def run_shard(work, hot_path, keep=None):
+    """One pass over a rank's buckets: ``hot_path(z, mask, speakers)`` -> padded waveforms
+    [n, 1, 256 * longest].  ``keep`` is None (drop outputs), "all", or a set of bucket ids whose
+    output is returned as {bucket id: waveform}."""
+    kept = {}
+    for b in work:
+        wav = hot_path(b.z, b.mask, b.speakers)
+        if keep == "all" or (keep is not None and b.bucket_id in keep):
+            kept[b.bucket_id] = wav
+    return kept
+
+
+def valid_checksum(work, outputs, hop: int = 256) -> float:
+    """Sum of the valid samples of every kept output (float64), a per-rank fingerprint that
+    does not depend on how buckets were dealt to ranks."""
+    total = 0.0
+    for b in work:
+        wav = outputs.get(b.bucket_id)
+        if wav is None:
+            continue
+        t = torch.arange(wav.shape[-1], device=wav.device).unsqueeze(0)
+        valid = t < (b.lengths.to(wav.device) * hop).unsqueeze(1)
+        total += float((wav[:, 0].double() * valid).sum())
+    return total
+
+
+def metrics_row(elapsed, work, parity=0.0, checksum=0.0):
+    row = [0.0] * METRIC_COLUMNS
+    row[M_ELAPSED] = float(elapsed)
+    row[M_VALID_FRAMES] = float(sum(b.valid_frames for b in work))
+    row[M_PADDED_FRAMES] = float(sum(b.padded_frames for b in work))
+    row[M_UTTERANCES] = float(sum(len(b.utterances) for b in work))
+    row[M_PARITY] = float(parity)
+    row[M_CHECKSUM] = float(checksum)
+    return row
