@@ -65,6 +65,10 @@ def parse(argv=None):
                     help="skip the short runs of the other precision modes after the timed region")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the text_to_speech / single-utterance decoder / voice-conversion lines")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL over xGMI, the real thing) or gloo (rehearsals on a box with fewer GPUs)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: ranks map onto the visible GPUs modulo their number")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (all threads)")
     return ap.parse_args(argv)
 
@@ -158,6 +162,8 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    if args.share_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     engine.set_precision(args.precision)
@@ -165,7 +171,11 @@ def main():
     if world > 1 or "RANK" in os.environ:           # a rank of a multi-process job, any world size
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    mdev = dev if (dist is not None and args.dist_backend == "nccl") else None     # where metric rows are gathered
 
     torch.set_grad_enabled(False)
     sd = synth.hot_path_state_dict(SEED, with_posterior=False)
@@ -210,7 +220,7 @@ def main():
             checked.append({"bucket": b.bucket_id, "utterance": int(b.utterances[i]), "frames": int(b.lengths[i]),
                             "max_abs": float(diff.max()), "max_abs_valid": float(diff[..., :n].max())})
         row = sharding.metrics_row(el, work, parity=worst, checksum=sharding.valid_checksum(work, kept))
-        table = sharding.gather_metrics(row, device=dev if dist is not None else None)
+        table = sharding.gather_metrics(row, device=mdev)
         out = sharding.summarize(table, steps)
         out.update({"utterances": args.corpus, "steps": steps, "scaling": "strong", "checked_rank0": checked,
                     "tol": tol, "buckets_per_rank": [len(work)] if dist is None else None})
@@ -280,7 +290,7 @@ def main():
     row[sharding.M_UTTERANCES] = utts_local
     row[sharding.M_PARITY] = parity_local
     row[sharding.M_CHECKSUM] = float(wav.double().sum())
-    table = sharding.gather_metrics(row, device=dev if dist is not None else None)
+    table = sharding.gather_metrics(row, device=mdev)
     job = sharding.summarize(table, args.steps)        # whole-job value = all ranks' audio / slowest rank's time
     failures = []
     if job["parity_max_abs"] > tol:

@@ -14,7 +14,8 @@
  *    allocate, free or synchronise, so they may be captured into a HIP graph;
  *  - return value 0 = success, negative = error (VK_E_*); vk_last_error() returns a
  *    thread-local message for the last failing call on this thread;
- *  - no mutable global state beyond that thread-local message: calls are re-entrant.
+ *  - no mutable global state beyond that thread-local message and once-per-device kernel
+ *    attributes: calls are re-entrant, and the library reads no environment variable.
  */
 #ifndef VITS_AMD_H
 #define VITS_AMD_H
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 2
+#define VK_ABI_VERSION 3
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -122,6 +123,9 @@ typedef struct {
 
 int         vk_abi_version(void);
 const char* vk_last_error(void);
+/* sizeof of a struct as the library was compiled, so that a binding can check its own mirror:
+ * which = 0 vk_conv_args, 1 vk_pair_args, 2 vk_wn_args, 3 vk_tile_info; 0 for an unknown id. */
+size_t      vk_sizeof_args(int which);
 int         vk_tile_query(int tile, vk_tile_info* info);
 
 /* Dynamic LDS bytes one workgroup of this launch uses (diagnostic; <= 160 KiB). */

@@ -37,6 +37,25 @@ def test_int16_conversion():
     assert frontend.to_int16(w).tolist() == [-32767, -32767, -16384, 0, 8192, 32767, 32767]
 
 
+def test_wav_writer_round_trip(tmp_path):
+    """16-bit PCM file as the reference's scripts leave it (22050 Hz, one channel): header fields
+    and samples survive a round trip, within half a quantisation step."""
+    import wave
+    wav = _wav(22050)[:, :22050] * 1.5                      # some samples clip
+    frontend.save_wav(tmp_path / "o.wav", wav, 22050)
+    with wave.open(str(tmp_path / "o.wav"), "rb") as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, 22050, 22050)
+    back, rate = frontend.load_wav(tmp_path / "o.wav")
+    assert rate == 22050 and back.shape == wav.shape
+    assert (back - wav.clamp(-1, 1)).abs().max().item() <= 0.5 / 32767 + 1e-7
+    stereo = torch.stack([wav[0, :100], -wav[0, :100]])
+    frontend.save_wav(tmp_path / "s.wav", stereo)
+    back2, _ = frontend.load_wav(tmp_path / "s.wav")
+    assert back2.shape == (2, 100) and torch.allclose(back2[0], -back2[1])
+    with pytest.raises(ValueError):
+        frontend.save_wav(tmp_path / "bad.wav", torch.zeros(1, 1, 8))
+
+
 @pytest.mark.gpu
 def test_power_spectrogram_gpu_feeds_voice_conversion():
     from vits_amd.module.vits_generator import HotPathGenerator

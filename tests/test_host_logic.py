@@ -124,15 +124,50 @@ def test_generate_path_and_mask():
     assert sequence_mask(torch.tensor([2, 4])).tolist() == [[True, True, False, False], [True] * 4]
 
 
-def test_library_exports_every_declared_symbol():
+def test_library_exports_exactly_the_declared_symbols():
+    """Declared in include/vits_amd.h <=> exported with C linkage: nothing missing, and no
+    undeclared entry point (diagnostic hooks live in the separate -DVK_DIAG build)."""
+    import subprocess
     header = open(os.path.join(ROOT, "include", "vits_amd.h")).read()
     declared = set(re.findall(r"\b(vk_[a-z0-9_]+)\s*\(", header))
     assert {"vk_conv1d", "vk_speaker_linear", "vk_post_conv_tanh", "vk_abi_version",
-            "vk_last_error", "vk_tile_query", "vk_conv1d_lds_bytes"} <= declared
+            "vk_last_error", "vk_tile_query", "vk_conv1d_lds_bytes", "vk_sizeof_args"} <= declared
     lib = ctypes.CDLL(native.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/vits_amd.h but not exported"
-    assert native.lib().vk_abi_version() == 2
+    nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True)
+    exported = {ln.split()[-1] for ln in nm.stdout.splitlines() if ln.split() and ln.split()[-1].startswith("vk_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    assert native.lib().vk_abi_version() == native.header_abi_version()
+
+
+def test_binding_structs_match_the_library():
+    L = native.lib()
+    for which, mirror in enumerate((native.ConvArgs, native.PairArgs, native.WnArgs, native.TileInfo)):
+        assert L.vk_sizeof_args(which) == ctypes.sizeof(mirror), mirror.__name__
+    assert L.vk_sizeof_args(99) == 0
+
+
+def test_product_library_reads_no_environment():
+    """The switches for timing experiments exist only in the diagnostic build."""
+    blob = open(native.LIB_PATH, "rb").read()
+    for name in (b"VK_DEBUG_SKIP", b"VK_LDS_MIN", b"VK_NO_VEC", b"VK_XCD_MAP", b"vk_debug_set_stamps"):
+        assert name not in blob, name
+
+
+def _conv_args(**kw):
+    """A plausible vk_conv_args for host-side validation (pointers are never dereferenced)."""
+    a = native.ConvArgs()
+    B, C, L = 2, 32, 1024
+    a.x, a.x_bstride, a.x_cstride = 0x10000000, C * L, L
+    a.w = 0x20000000
+    a.out, a.out_bstride, a.out_cstride = 0x30000000, C * L, L
+    a.batch, a.c_in, a.c_out, a.length = B, C, C, L
+    a.taps, a.dilation, a.pad = 3, 1, 1
+    a.tile, a.epilogue, a.act_in, a.in_slope = native.TILE_M32, native.EPI_STORE, 1, 0.1
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
 
 
 def test_argument_validation_without_gpu():
@@ -143,6 +178,27 @@ def test_argument_validation_without_gpu():
     assert b"null" in L.vk_last_error()
     assert L.vk_post_conv_tanh(None, None, None, 1, 1, 1, 7, 0.01, None) == -1
     assert L.vk_speaker_linear(None, None, None, None, 1, 1, 1, None) == -1
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args())) > 0
+    # an output on top of the input races with the neighbours' halo reads: rejected
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args(out=0x10000000))) == -1
+    assert b"overlaps" in L.vk_last_error()
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args(out=0x10000000 + 4 * 1024 * 63))) == -1    # partial overlap
+    two = _conv_args(epilogue=native.EPI_RESID_ACC, res=0x40000000, res_bstride=32 * 1024, res_cstride=1024,
+                     out2=0x10000000, out2_bstride=32 * 1024, out2_cstride=1024)
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(two)) == -1 and b"out2 overlaps" in L.vk_last_error()
+    # a 1x1 convolution with a single row block may run in place (each workgroup reads only what it owns)
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args(out=0x10000000, taps=1, pad=0))) > 0
+    # ... but not with several row blocks (another workgroup reads the same tile)
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args(out=0x10000000, taps=1, pad=0, c_out=64))) == -1
+
+
+def test_vector_staging_falls_back_when_its_alignment_slack_does_not_fit():
+    """halo 64 with an odd left padding: the 16-byte stager would need 68 extra columns, the
+    4-byte stager fits in the 64-column slack of the LDS row."""
+    L = native.lib()
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args(taps=65, pad=32))) > 0
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args(taps=65, pad=31))) > 0
+    assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args(taps=66, pad=32))) == -2       # halo 65 never fits
 
 
 def test_cpu_tensors_fail_loudly():

@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, ".")
 from vits_amd import native, packing
 
+native.use_diagnostic_library()      # build it with `python -m vits_amd.build --diag`
+
 C, K, DIL, B, L = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 16, int(sys.argv[4])
 dev = torch.device("cuda:0")
 lib = native.lib()

@@ -5,6 +5,8 @@ import sys
 import torch
 sys.path.insert(0, ".")
 from vits_amd import native, packing
+
+native.use_diagnostic_library()      # build it with `python -m vits_amd.build --diag`
 from vits_amd.engine import choose_tile
 
 cin, cout, s, B, L = (int(a) for a in sys.argv[1:6])

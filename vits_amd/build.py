@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libvits_amd.so")
+DIAG_LIB = os.path.join(LIBDIR, "libvits_amd_diag.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
@@ -31,37 +32,40 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src: str, force: bool, hdr_mtime: float) -> str:
-    obj = os.path.join(OBJDIR, src[:-4] + ".o")
+def _compile(src: str, force: bool, hdr_mtime: float, diag: bool = False) -> str:
+    obj = os.path.join(OBJDIR + ("_diag" if diag else ""), src[:-4] + ".o")
     path = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_mtime)):
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", path, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *(["-DVK_DIAG"] if diag else []), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
     return obj
 
 
-def build(force: bool = False, jobs: int | None = None) -> str:
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(force: bool = False, jobs: int | None = None, diag: bool = False) -> str:
+    """The product library, or with ``diag`` the diagnostic build (``-DVK_DIAG``: environment
+    switches for timing experiments and per-workgroup time stamps; only tools/ load it)."""
+    lib = DIAG_LIB if diag else LIB
+    os.makedirs(OBJDIR + ("_diag" if diag else ""), exist_ok=True)
     srcs = _sources()
     hdr_mtime = _headers_mtime()
     # a library newer than every source is up to date even where the object files did not travel
     newest = max([hdr_mtime] + [os.path.getmtime(os.path.join(CSRC, f)) for f in srcs])
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) > newest:
-        return LIB
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) > newest:
+        return lib
     jobs = jobs or min(8, len(srcs))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, hdr_mtime), srcs))
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        objs = list(ex.map(lambda s: _compile(s, force, hdr_mtime, diag), srcs))
+    if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, diag="--diag" in sys.argv))

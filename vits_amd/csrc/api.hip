@@ -19,12 +19,31 @@ int vk_fail(int code, const char* msg)
     return code;
 }
 
+// The diagnostic build (-DVK_DIAG, libvits_amd_diag.so, loaded only by tools/) adds switches for
+// timing experiments: environment variables that drop parts of a kernel or change the launch
+// geometry, and per-workgroup time stamps.  The product library has none of them: it reads no
+// environment variable and exports nothing the header does not declare.
+#ifdef VK_DIAG
 static unsigned long long* g_stamps = nullptr;
-// Diagnostic only (not part of the public header): per-workgroup time stamps of later launches.
 extern "C" void vk_debug_set_stamps(void* dev_buffer) { g_stamps = (unsigned long long*)dev_buffer; }
+static int diag_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static constexpr unsigned long long* g_stamps = nullptr;
+static int diag_env(const char*, int dflt) { return dflt; }
+#endif
 
 extern "C" int vk_abi_version(void) { return VK_ABI_VERSION; }
 extern "C" const char* vk_last_error(void) { return g_err; }
+extern "C" size_t vk_sizeof_args(int which)
+{
+    switch (which) {
+    case 0: return sizeof(vk_conv_args);
+    case 1: return sizeof(vk_pair_args);
+    case 2: return sizeof(vk_wn_args);
+    case 3: return sizeof(vk_tile_info);
+    default: return 0;
+    }
+}
 
 extern "C" int vk_tile_query(int tile, vk_tile_info* info)
 {
@@ -117,7 +136,7 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     const int ck = split ? VK_SPLIT_CK : (bf16 ? kBf16Ck[a->tile] : G.ck);
     d->nchunk = (a->c_in + ck - 1) / ck;
     // 16-byte staging when every row of x starts 16-byte aligned and the length is a multiple of 4
-    static const int no_vec = getenv("VK_NO_VEC") != nullptr;
+    static const int no_vec = diag_env("VK_NO_VEC", 0);
     *vec = !no_vec && !bf16 && a->act_in &&
            ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) && (a->length % 4 == 0) &&
            (a->epilogue == VK_EPI_STORE || a->epilogue == VK_EPI_RESID || a->epilogue == VK_EPI_RESID_ACC ||
@@ -131,28 +150,49 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
         d->xw = TN + halo;
     }
     d->lds_stride = TN + 64;              // compile-time constant of the kernel
+    if (*vec && d->xw > d->lds_stride) {  // the 4-column alignment slack does not fit: 4-byte staging does
+        *vec = 0;
+        d->col0 = 0;
+        d->xw = TN + halo;
+    }
     if (d->xw > d->lds_stride)
         return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: time tile + halo does not fit the staged LDS row");
     d->groups_per_mt = d->nchunk * a->taps * (split ? 3 * (ck / 16) : (bf16 ? ck / 16 : ck / 8));
-    static const int dbg = getenv("VK_DEBUG_SKIP") ? atoi(getenv("VK_DEBUG_SKIP")) : 0;
+    static const int dbg = diag_env("VK_DEBUG_SKIP", 0);
     d->dbg = dbg;
     d->stamps = g_stamps;
     const int rows_blk = 32 * G.a_rep * G.wm;
     const int64_t rows = gemm_rows(a);
     d->n_tiles = (a->length + TN - 1) / TN;
     d->n_rowblk = (int)((rows + rows_blk - 1) / rows_blk);
+    if (halo > 0 || d->n_rowblk > 1) {
+        // other workgroups read these columns of x (halo) or the same tile (further row blocks)
+        // at any time during the launch, so no output may land on x
+        auto whole = [&](const void* p, int64_t bstride, int64_t bytes, const char*& lo, const char*& hi) {
+            lo = (const char*)p;
+            hi = lo + (int64_t)(a->batch - 1) * (bstride < 0 ? -bstride : bstride) * 4 + bytes;
+        };
+        const char *x0, *x1, *o0, *o1;
+        whole(a->x, a->x_bstride, xb, x0, x1);
+        whole(a->out, a->out_bstride, ob, o0, o1);
+        if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_conv1d: out overlaps x (taps > 1 or several row blocks)");
+        if (a->out2) {
+            whole(a->out2, a->out2_bstride, o2, o0, o1);
+            if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_conv1d: out2 overlaps x (taps > 1 or several row blocks)");
+        }
+    }
     // Placing the row blocks of a time tile on one XCD cuts the fetched bytes of the multi-row-block
     // launches by 2-4x (one HBM read of the x tile per XCD instead of one per row block).  It pays where
     // the kernel is HBM-bound (bf16 inputs); the fp32 kernels are MFMA-bound and run 0.4 % slower with it.
-    // VK_XCD_MAP=0 / 1 forces it off / on for every precision.
-    static const int xcd_env = getenv("VK_XCD_MAP") ? atoi(getenv("VK_XCD_MAP")) : -1;
+    // (Diagnostic build: VK_XCD_MAP=0 / 1 forces it off / on for every precision.)
+    static const int xcd_env = diag_env("VK_XCD_MAP", -1);
     d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : a->precision == VK_PREC_BF16);
     if (d->xcd_map)
         *grid = dim3((unsigned)(8 * ((d->n_tiles + 7) / 8) * d->n_rowblk), 1, (unsigned)a->batch);
     else
         *grid = dim3((unsigned)d->n_tiles, (unsigned)d->n_rowblk, (unsigned)a->batch);
     *lds = bf16 ? (size_t)2 * (TN + 64) * ((split ? 3 : 1) * ck * 2 + 16) : (size_t)2 * G.ck * d->lds_stride * sizeof(float);
-    static const int lds_min = getenv("VK_LDS_MIN") ? atoi(getenv("VK_LDS_MIN")) : 0;   // occupancy experiments
+    static const int lds_min = diag_env("VK_LDS_MIN", 0);   // occupancy experiments
     if ((int)*lds < lds_min) *lds = lds_min;
     if (*lds > 160 * 1024) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: LDS tile exceeds 160 KiB");
     return VK_OK;
@@ -290,7 +330,7 @@ extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
     c.epilogue = a->epilogue; c.act_in = 1; c.in_slope = a->slope; c.navg = a->navg;
     q.c.x_bytes = (unsigned)xb; q.c.out_bytes = (unsigned)ob; q.c.res_bytes = (unsigned)xb; q.c.out2_bytes = (unsigned)ab;
     q.c.nchunk = a->channels / ck;
-    static const int no_vec = getenv("VK_NO_VEC") != nullptr;
+    static const int no_vec = diag_env("VK_NO_VEC", 0);
     const int vec = !no_vec && !bf16 && ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) &&
                     (a->length % 4 == 0);
     if (vec) {
@@ -363,7 +403,7 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
     c.first = a->first; c.hidden = a->hidden;
     q.c.x_bytes = (unsigned)xb; q.c.out_bytes = (unsigned)ob; q.c.res_bytes = (unsigned)xb; q.c.out2_bytes = (unsigned)sb;
     q.c.nchunk = a->hidden / VK_WN_CK;
-    static const int no_vec = getenv("VK_NO_VEC") != nullptr;
+    static const int no_vec = diag_env("VK_NO_VEC", 0);
     const int vec = !no_vec && ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) &&
                     (a->length % 4 == 0);
     if (vec) {

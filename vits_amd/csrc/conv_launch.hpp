@@ -35,13 +35,8 @@ int vk_launch_tile3n(int epi, int act, int vec, const ConvDev& d, dim3 grid, siz
 #define VK_CONV_CASE(EPI, ACT, VEC)                                                              \
     if (epi == (EPI) && act == (ACT) && vec == (VEC)) {                                          \
         auto k = conv_mfma_kernel<G.a_rep, G.b_rep, G.wm, G.wn, G.ck, (EPI), (ACT) != 0, (VEC) != 0>; \
-        static size_t lds_allowed = 65536;      /* raised once per instantiation, outside any graph capture */ \
-        if (lds > lds_allowed) {                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return (int)e;                                                  \
-            lds_allowed = 160 * 1024;                                                            \
-        }                                                                                        \
+        static std::atomic<unsigned long long> lds_raised{0};   /* bit d: limit raised on device d */\
+        if (hipError_t e = vk_allow_lds(k, lds, lds_raised); e != hipSuccess) return (int)e;     \
         hipLaunchKernelGGL(k, grid, dim3(64 * G.wm * G.wn), lds, s, d);                          \
         return (int)hipGetLastError();                                                           \
     }

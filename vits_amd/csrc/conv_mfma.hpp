@@ -21,10 +21,28 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <type_traits>
 #include "../../include/vits_amd.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// A kernel may use more than 64 KiB of dynamic LDS only after the limit has been raised for it
+// on the device it is launched on.  `raised` belongs to one kernel instantiation: bit d says
+// that device d has been done (devices 64 apart share a bit, which costs one redundant call).
+template <typename K>
+inline hipError_t vk_allow_lds(K kernel, size_t lds, std::atomic<unsigned long long>& raised)
+{
+    if (lds <= 65536) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (raised.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) raised.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 struct ConvDev {
     vk_conv_args a;
@@ -34,13 +52,13 @@ struct ConvDev {
     int groups_per_mt;  // 64-lane x float4 groups per 32-row tile: nchunk * taps * CK / 8
     int col0;           // staged column of time t0 - pad (vector staging starts at a multiple of 4 columns)
     unsigned x_bytes, out_bytes, res_bytes, out2_bytes;   // byte spans of one batch item's views (buffer bounds)
-    unsigned long long* stamps;   // diagnostic: 8 x u64 per workgroup (times, placement) or null
+    unsigned long long* stamps;   // diagnostic build only: 8 x u64 per workgroup (times, placement) or null
     int n_tiles;        // time tiles per batch item
     int n_rowblk;       // row blocks; > 1 with xcd_map: blockIdx.x enumerates (XCD, row block, tile group)
     int xcd_map;        // 1: workgroups that share a staged x tile (all row blocks of a time tile) are
                         // placed on the same XCD in consecutive dispatch slots, so the tile is fetched
                         // from HBM once per XCD instead of once per row block
-    int dbg;            // timing experiments only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop,
+    int dbg;            // diagnostic build only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop,
                         // 4 = stage only the first chunk, 8 = barrier only on the first chunk
 };
 
@@ -201,10 +219,19 @@ struct VectorStager {
     }
 };
 
+// Timing experiments (time stamps per workgroup, kernels with parts left out) exist only in the
+// diagnostic build of the library (-DVK_DIAG, libvits_amd_diag.so); in the product build the
+// conditions below are compile-time false and the code is gone.
+#ifdef VK_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
+
 // Diagnostic time stamps (100 MHz constant clock); written only when a stamp buffer is set.
 __device__ __forceinline__ void vk_stamp(const ConvDev& d, int slot)
 {
-    if (d.stamps != nullptr && threadIdx.x == 0) {
+    if (kDiag && d.stamps != nullptr && threadIdx.x == 0) {
         const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         d.stamps[(size_t)lin * 8 + slot] = __builtin_amdgcn_s_memrealtime();
         if (slot == 0) d.stamps[(size_t)lin * 8 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))
@@ -618,13 +645,15 @@ conv_mfma_kernel(const ConvDev d)
     for (int chunk = 0; chunk < d.nchunk; ++chunk) {
         float* buf = lds + (chunk & 1) * (CK * STRIDE);
         unsigned long long tb0 = 0;
-        if (d.stamps) tb0 = __builtin_amdgcn_s_memrealtime();
-        if (!(d.dbg & 4) || chunk == 0) store_chunk(chunk, buf);
-        if (!(d.dbg & 8) || chunk == 0) __syncthreads();
+        const int dbg = kDiag ? d.dbg : 0;
+        const bool stamping = kDiag && d.stamps != nullptr;
+        if (stamping) tb0 = __builtin_amdgcn_s_memrealtime();
+        if (!(dbg & 4) || chunk == 0) store_chunk(chunk, buf);
+        if (!(dbg & 8) || chunk == 0) __syncthreads();
         if (chunk == 0) vk_stamp(d, 1);
-        else if (d.stamps) boundary_ticks += __builtin_amdgcn_s_memrealtime() - tb0;
-        if (chunk + 1 < d.nchunk && !(d.dbg & 4)) issue_loads(chunk + 1);
-        if (d.dbg & 2) continue;
+        else if (stamping) boundary_ticks += __builtin_amdgcn_s_memrealtime() - tb0;
+        if (chunk + 1 < d.nchunk && !(dbg & 4)) issue_loads(chunk + 1);
+        if (dbg & 2) continue;
 
         // k-steps walk channel pairs within a tap, then taps; the B fragments of the next
         // k-step are read from LDS before the current k-step's MFMAs are issued.  Within a tap
@@ -675,8 +704,8 @@ conv_mfma_kernel(const ConvDev d)
     }
 
     vk_stamp(d, 2);
-    if (d.stamps != nullptr && threadIdx.x == 0)
+    if (kDiag && d.stamps != nullptr && threadIdx.x == 0)
         d.stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 4] = boundary_ticks;
-    if ((d.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    if (kDiag && (d.dbg & 1) && acc[0][0][0] != 12345.678f) return;
     conv_epilogue<A_REP, B_REP, EPI>(d, acc, b, t0, mt0, wn, half, l31);
 }

@@ -4,13 +4,8 @@
 #define VK_PAIR_CASE(G, CH, EPI, VEC)                                                            \
     if (channels == (CH) && epi == (EPI) && vec == (VEC)) {                                    \
         auto k = resblock_pair_kernel<G.b_rep, G.wm, G.wn, G.ck, (EPI), (VEC) != 0>;             \
-        static size_t lds_allowed = 65536;                                                       \
-        if (lds > lds_allowed) {                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return (int)e;                                                  \
-            lds_allowed = 160 * 1024;                                                            \
-        }                                                                                        \
+        static std::atomic<unsigned long long> lds_raised{0};   /* bit d: limit raised on device d */\
+        if (hipError_t e = vk_allow_lds(k, lds, lds_raised); e != hipSuccess) return (int)e;     \
         hipLaunchKernelGGL(k, grid, dim3(64 * G.wm * G.wn), lds, s, q);                          \
         return (int)hipGetLastError();                                                           \
     }

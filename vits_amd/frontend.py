@@ -32,3 +32,34 @@ def power_spectrogram(wav: torch.Tensor, filter_length: int = 1024, hop_length: 
 def to_int16(wav: torch.Tensor) -> torch.Tensor:
     """Waveform in [-1, 1] -> 16-bit PCM samples (what a wav writer stores)."""
     return (wav.clamp(-1.0, 1.0) * 32767.0).round().to(torch.int16)
+
+
+def save_wav(path, wav: torch.Tensor, sample_rate: int = 22050) -> None:
+    """Write a [channels, N] (or [N]) float waveform as 16-bit PCM, the last step of
+    /root/reference/vits_voice_converter.py:103-104 and vits_text_to_speech.py:107
+    (``torchaudio.save(path, output_wav, sample_rate)``).  Standard-library ``wave`` writer;
+    samples are interleaved by channel as the RIFF format wants them."""
+    import wave
+    if wav.dim() == 1:
+        wav = wav.unsqueeze(0)
+    if wav.dim() != 2:
+        raise ValueError(f"save_wav expects [channels, samples], got {tuple(wav.shape)}")
+    pcm = to_int16(wav.detach().to("cpu", torch.float32)).t().contiguous()      # [N, channels]
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(pcm.shape[1])
+        f.setsampwidth(2)
+        f.setframerate(int(sample_rate))
+        f.writeframes(pcm.numpy().astype("<i2").tobytes())
+
+
+def load_wav(path):
+    """Read 16-bit PCM written by ``save_wav`` back as ([channels, N] float in [-1, 1], rate)."""
+    import wave
+
+    import numpy as np
+    with wave.open(str(path), "rb") as f:
+        if f.getsampwidth() != 2:
+            raise ValueError("only 16-bit PCM is supported")
+        ch, rate, n = f.getnchannels(), f.getframerate(), f.getnframes()
+        pcm = np.frombuffer(f.readframes(n), dtype="<i2").reshape(n, ch)
+    return torch.from_numpy(pcm.astype(np.float32) / 32767.0).t().contiguous(), rate

@@ -144,19 +144,19 @@ class VitsGenerator(HotPathGenerator):
         from ..graphs import GraphedCall
         if not hasattr(self, "_front_graphs"):
             self._front_graphs = {}
-        key = (tuple(text_padded.shape), str(text_padded.device), float(length_scale), float(noise_scale_w),
-               noise_w is not None)
+        if noise_w is None:
+            # The duration predictor's draw stays outside the graph: captured, it would be frozen
+            # at its capture-time value (and a host-to-device copy is not capturable).  Same
+            # draw as the eager path (CPU generator, then copied), fed to the graph as an input.
+            noise_w = torch.randn(text_padded.size(0), 2, text_padded.size(1)).to(
+                device=text_padded.device, dtype=torch.float32)
+        key = (tuple(text_padded.shape), str(text_padded.device), float(length_scale), float(noise_scale_w))
         call = self._front_graphs.get(key)
         if call is None:
-            if noise_w is not None:
-                call = GraphedCall(lambda t, l, s, n: self._token_stage(t, l, s, n, length_scale, noise_scale_w),
-                                   text_padded, text_lengths, speaker_id, noise_w)
-            else:
-                call = GraphedCall(lambda t, l, s: self._token_stage(t, l, s, None, length_scale, noise_scale_w),
-                                   text_padded, text_lengths, speaker_id)
+            call = GraphedCall(lambda t, l, s, n: self._token_stage(t, l, s, n, length_scale, noise_scale_w),
+                               text_padded, text_lengths, speaker_id, noise_w)
             self._front_graphs[key] = call
-        args = (text_padded, text_lengths, speaker_id) + ((noise_w,) if noise_w is not None else ())
-        m_p, logs_p, text_mask, w_ceil, g = call(*args)
+        m_p, logs_p, text_mask, w_ceil, g = call(text_padded, text_lengths, speaker_id, noise_w)
         return m_p, logs_p, text_mask, w_ceil, g.clone()     # g outlives this call; the rest is consumed at once
 
     @torch.no_grad()

@@ -12,6 +12,15 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvits_amd.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libvits_amd_diag.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vits_amd.h")
+
+
+def header_abi_version() -> int:
+    """VK_ABI_VERSION as include/vits_amd.h declares it (the binding below mirrors that header)."""
+    import re
+    with open(HEADER_PATH) as f:
+        return int(re.search(r"#define\s+VK_ABI_VERSION\s+(\d+)", f.read()).group(1))
 
 TILE_M128, TILE_M64, TILE_M32, TILE_PAIR = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_F32_SPLIT = 0, 1, 2
@@ -81,16 +90,26 @@ class NativeError(RuntimeError):
 
 
 _lib = None
+_lib_path = LIB_PATH
+
+
+def use_diagnostic_library():
+    """Timing tools only: load the -DVK_DIAG build (environment switches, time stamps) instead
+    of the product library.  Must be called before the first kernel call of the process."""
+    global _lib_path
+    if _lib is not None:
+        raise NativeError("the library is already loaded")
+    _lib_path = DIAG_LIB_PATH
 
 
 def lib():
     """The loaded library; raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise NativeError(f"{LIB_PATH} not found: run `python -m vits_amd.build` "
+        if not os.path.exists(_lib_path):
+            raise NativeError(f"{_lib_path} not found: run `python -m vits_amd.build` "
                               "(there is no CPU fallback for the HIP path)")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(_lib_path)
         L.vk_abi_version.restype = C.c_int
         L.vk_last_error.restype = C.c_char_p
         L.vk_tile_query.argtypes = [C.c_int, C.POINTER(TileInfo)]
@@ -104,8 +123,16 @@ def lib():
         L.vk_resblock_pair.argtypes = [C.POINTER(PairArgs), C.c_void_p]
         L.vk_wn_query.argtypes = [C.c_int, C.POINTER(TileInfo)]
         L.vk_wn_layer.argtypes = [C.POINTER(WnArgs), C.c_void_p]
-        if L.vk_abi_version() != 2:
-            raise NativeError("libvits_amd.so ABI version mismatch")
+        L.vk_sizeof_args.argtypes = [C.c_int]
+        L.vk_sizeof_args.restype = C.c_size_t
+        want = header_abi_version()
+        if L.vk_abi_version() != want:
+            raise NativeError(f"{_lib_path}: ABI version {L.vk_abi_version()}, include/vits_amd.h declares {want}; "
+                              "rebuild with `python -m vits_amd.build`")
+        for which, mirror in enumerate((ConvArgs, PairArgs, WnArgs, TileInfo)):
+            if L.vk_sizeof_args(which) != C.sizeof(mirror):
+                raise NativeError(f"{mirror.__name__} is {C.sizeof(mirror)} bytes here, "
+                                  f"{L.vk_sizeof_args(which)} in the library: native.py is out of step with the header")
         _lib = L
     return _lib
 
