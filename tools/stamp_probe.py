@@ -11,17 +11,21 @@ from vits_amd import native, packing
 native.use_diagnostic_library()      # build it with `python -m vits_amd.build --diag`
 
 C, K, DIL, B, L = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 16, int(sys.argv[4])
+PREC = sys.argv[5] if len(sys.argv) > 5 else "fp32"
+from vits_amd import engine
+engine.set_precision(PREC)
 dev = torch.device("cuda:0")
 lib = native.lib()
 lib.vk_debug_set_stamps.argtypes = [ctypes.c_void_p]
 tile = native.TILE_M128 if C >= 128 else (native.TILE_M64 if C == 64 else native.TILE_M32)
 ti = native.tile_info(tile)
 w = torch.randn(C, C, K) / (C * K) ** 0.5
-wp = packing.pack_conv_weight(w, ti.ck, ti.rows_per_block).to(dev)
-bias = torch.randn(C, device=dev)
+pc = engine.PackedConv(w, torch.randn(C), dev, dilation=DIL, tile=tile)
+wp, bias = pc.w, pc.bias
 x = torch.randn(B, C, L, device=dev)
 out = torch.empty_like(x)
-nblk = ((L + ti.time_tile - 1) // ti.time_tile) * ((C + ti.rows_per_block - 1) // ti.rows_per_block) * B
+time_tile = {"fp32": ti.time_tile, "fp32-split": 256 if tile == native.TILE_M32 else ti.time_tile, "bf16": ti.time_tile}[PREC]
+nblk = ((L + time_tile - 1) // time_tile) * ((C + ti.rows_per_block - 1) // ti.rows_per_block) * B
 stamps = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
 def run():
     native.conv1d(x, wp, out, c_in=C, c_out=C, taps=K, dilation=DIL, pad=(K - 1) * DIL // 2, tile=tile,

@@ -191,7 +191,10 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
         *grid = dim3((unsigned)(8 * ((d->n_tiles + 7) / 8) * d->n_rowblk), 1, (unsigned)a->batch);
     else
         *grid = dim3((unsigned)d->n_tiles, (unsigned)d->n_rowblk, (unsigned)a->batch);
-    *lds = bf16 ? (size_t)2 * (TN + 64) * ((split ? 3 : 1) * ck * 2 + 16) : (size_t)2 * G.ck * d->lds_stride * sizeof(float);
+    *lds = split ? vk_split_lds_bytes(TN, ck)
+         : (bf16 ? (size_t)2 * (TN + 64) * (ck * 2 + 16) : (size_t)2 * G.ck * d->lds_stride * sizeof(float));
+    if (split && (int64_t)d->n_tiles * d->n_rowblk * a->batch > 0x7fffffffLL)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: more than 2^31 tiles in one launch");
     static const int lds_min = diag_env("VK_LDS_MIN", 0);   // occupancy experiments
     if ((int)*lds < lds_min) *lds = lds_min;
     if (*lds > 160 * 1024) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d: LDS tile exceeds 160 KiB");

@@ -2,15 +2,6 @@
 #include "conv_launch.hpp"
 #include "conv_split.hpp"
 
-#define VK_SPLIT_CASE(EPI, ACT)                                                                   \
-    if (epi == (EPI) && act == (ACT)) {                                                          \
-        auto k = conv_split_kernel<G.a_rep, G.b_rep, G.wm, G.wn, CKB, (EPI), (ACT) != 0>;         \
-        static std::atomic<unsigned long long> lds_raised{0};   /* bit d: limit raised on device d */\
-        if (hipError_t e = vk_allow_lds(k, lds, lds_raised); e != hipSuccess) return (int)e;     \
-        hipLaunchKernelGGL(k, grid, dim3(64 * G.wm * G.wn), lds, s, d);                          \
-        return (int)hipGetLastError();                                                           \
-    }
-
 int vk_launch_split_tile0(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s)
 {
     constexpr TileGeom G = kSplitTiles[0];
