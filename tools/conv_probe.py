@@ -17,8 +17,12 @@ n = int(sys.argv[8]) if len(sys.argv) > 8 else 20
 engine.set_precision(prec)
 dev = torch.device("cuda:0")
 w = torch.randn(C, C, K) / (C * K) ** 0.5
+if os.environ.get('ZERO'):
+    w.zero_()
 pc = engine.PackedConv(w, torch.randn(C), dev, dilation=DIL)
 x = torch.randn(B, C, L, device=dev)
+if os.environ.get('ZERO'):
+    x.zero_()
 res = torch.randn(B, C, L, device=dev)
 out = torch.empty_like(x)
 
