@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 3
+#define VK_ABI_VERSION 4
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -124,7 +124,8 @@ typedef struct {
 int         vk_abi_version(void);
 const char* vk_last_error(void);
 /* sizeof of a struct as the library was compiled, so that a binding can check its own mirror:
- * which = 0 vk_conv_args, 1 vk_pair_args, 2 vk_wn_args, 3 vk_tile_info; 0 for an unknown id. */
+ * which = 0 vk_conv_args, 1 vk_pair_args, 2 vk_wn_args, 3 vk_tile_info, 4 vk_mrf_args; 0 for an
+ * unknown id. */
 size_t      vk_sizeof_args(int which);
 int         vk_tile_query(int tile, vk_tile_info* info);
 
@@ -185,6 +186,38 @@ typedef struct {
 
 int vk_wn_query(int hidden, vk_tile_info* info);
 int vk_wn_layer(const vk_wn_args* a, void* stream);
+
+/* ---- a whole multi-receptive-field stage in one launch ------------------------------
+ *   out = ( sum_r resblock_r(x) ) / n_blocks                       (decoder.py:119-125)
+ *   resblock_r: for each pair j: h = conv1_rj(lrelu(x_r)); x_r = conv2_rj(lrelu(h)) + x_r
+ *                                                                  (decoder.py:46-61)
+ * conv1_rj has taps[r] taps and dilation[r][j], conv2_rj taps[r] taps and dilation 1, both
+ * "same" padded.  The residual stream and the sum over the resblocks (kernel sizes) stay in
+ * registers, the activated conv inputs in LDS; only x is read and out written.  Built for
+ * VK_PREC_BF16 (bf16 matrix-core inputs, fp32 accumulation) and the channel widths
+ * vk_mrf_query accepts; the receptive half-width of every resblock,
+ * sum_j (taps[r]-1)/2 * (dilation[r][j] + 1), must not exceed 64.  Weights are packed like
+ * vk_resblock_pair's for VK_PREC_BF16 (vk_mrf_query reports ck_bf16 and rows_per_block).
+ * `out` must not overlap `x`.                                                          */
+#define VK_MRF_MAX_BLOCKS 4
+#define VK_MRF_MAX_PAIRS  4
+typedef struct {
+    const float* x;       int64_t x_bstride;   int64_t x_cstride;     /* stage input [B, C, L] */
+    float* out;           int64_t out_bstride; int64_t out_cstride;
+    int32_t batch, channels, length;
+    int32_t n_blocks, n_pairs;
+    int32_t taps[VK_MRF_MAX_BLOCKS];                                   /* odd */
+    int32_t dilation[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
+    const void*  w1[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
+    const float* bias1[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
+    const void*  w2[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
+    const float* bias2[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
+    float   slope;
+    int32_t precision;                                                 /* VK_PREC_BF16 */
+} vk_mrf_args;
+
+int vk_mrf_query(int channels, int precision, vk_tile_info* info);
+int vk_mrf_stage(const vk_mrf_args* a, void* stream);
 
 /* out[b, o] = bias[o] + sum_i W[o, i] * g[b, i]   (speaker-conditioning 1x1 convs on
  * [B, G, 1] inputs: decoder.py:91,112 `cond`; wn.py:41-42,66 `condition_layer`).

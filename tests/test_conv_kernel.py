@@ -472,3 +472,84 @@ def test_split_conv_over_a_wide_dynamic_range():
     err32 = (out32.cpu().double() - ref).abs().max().item()
     print(f"wide range: split {err:.2e}, fp32 MFMA {err32:.2e}, |ref|max {ref.abs().max().item():.2f}")
     assert err <= max(2.0 * err32, 1e-6)
+
+
+# ---- a whole multi-receptive-field stage in one launch (bf16 matrix inputs) ----
+def _mrf_reference(x, blocks, slope=0.1, rnd=None):
+    """decoder.py:119-125 around :46-61; ``rnd`` is applied to whatever enters a convolution
+    (the bf16 rounding of the matrix inputs made explicit, or nothing for plain fp32)."""
+    rnd = rnd or _r16
+    tot = torch.zeros_like(x)
+    for k, pairs in blocks:
+        xr = x
+        for w1, b1, w2, b2, d in pairs:
+            h = F.conv1d(rnd(F.leaky_relu(xr, slope)), rnd(w1), b1, padding=(k - 1) * d // 2, dilation=d)
+            xr = F.conv1d(rnd(F.leaky_relu(h, slope)), rnd(w2), b2, padding=(k - 1) // 2) + xr
+        tot = tot + xr
+    return tot / len(blocks)
+
+
+@pytest.mark.parametrize("ch,B,L,kernels,dils", [
+    (32, 2, 1, (3, 7, 11), (1, 3, 5)),
+    (32, 2, 37, (3, 7, 11), (1, 3, 5)),
+    (32, 3, 256, (3, 7, 11), (1, 3, 5)),       # exactly one workgroup of outputs
+    (32, 1, 257, (3, 7, 11), (1, 3, 5)),       # one column into the second workgroup
+    (32, 2, 1500, (3, 7, 11), (1, 3, 5)),
+    (64, 2, 463, (3, 7, 11), (1, 3, 5)),
+    (64, 1, 1031, (3, 7, 11), (1, 3, 5)),
+    (64, 2, 300, (5, 3), (2, 1)),              # two resblocks of two pairs
+    (32, 1, 700, (11,), (1, 3, 5)),            # a single resblock: the mean is the resblock
+    (32, 2, 900, (3, 7, 11), (5,)),            # one pair per resblock: no chain for a rounding flip to travel down
+    (64, 2, 900, (11, 7, 3), (1,)),
+])
+def test_bf16_fused_mrf_stage(ch, B, L, kernels, dils):
+    mi = native.mrf_info(ch, native.PREC_BF16)
+    assert mi is not None
+    x = _rand(B, ch, L, seed=201)
+    ref_blocks, dev_blocks = [], []
+    seed = 210
+    for k in kernels:
+        rp, dp = [], []
+        for d in dils:
+            w1 = _rand(ch, ch, k, seed=seed) / (ch * k) ** 0.5
+            w2 = _rand(ch, ch, k, seed=seed + 1) / (ch * k) ** 0.5
+            b1, b2 = _rand(ch, seed=seed + 2) * 0.3, _rand(ch, seed=seed + 3) * 0.3
+            seed += 4
+            rp.append((w1, b1, w2, b2, d))
+            dp.append((packing.pack_conv_weight_bf16(w1, mi.ck_bf16, mi.rows_per_block).to(DEV), b1.to(DEV),
+                       packing.pack_conv_weight_bf16(w2, mi.ck_bf16, mi.rows_per_block).to(DEV), b2.to(DEV), d))
+        ref_blocks.append((k, rp))
+        dev_blocks.append((k, dp))
+    ref = _mrf_reference(x, ref_blocks)
+    out = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.mrf_stage(x.to(DEV), out, dev_blocks, slope=0.1)
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    # Every conv input is rounded to bf16.  A value on a rounding boundary falls either way with the
+    # summation order (a few per 100k elements), and down a chain of pairs one such flip grows to the
+    # bf16 noise floor over its receptive cone.  So: within one bf16 step of the rounded reference
+    # everywhere, and as close to the unrounded fp32 result as the rounded reference itself is.
+    scale = max(1.0, ref.abs().max().item())
+    err = (got - ref).abs()
+    assert err.max().item() <= 4e-3 * scale, err.max().item()
+    if len(dils) == 1:
+        assert err.mean().item() <= 2e-6 * scale, err.mean().item()
+        assert (err > 1e-5 * scale).float().mean().item() <= 0.02
+    exact = _mrf_reference(x, ref_blocks, rnd=lambda t: t)
+    noise_ref = (ref - exact).pow(2).mean().sqrt().item()
+    noise_got = (got - exact).pow(2).mean().sqrt().item()
+    assert noise_got <= 1.1 * noise_ref + 1e-7, (noise_got, noise_ref)
+    assert err.pow(2).mean().sqrt().item() <= 1.5 * noise_ref + 1e-6
+
+
+def test_fused_mrf_stage_rejects_bad_arguments():
+    assert native.mrf_info(128, native.PREC_BF16) is None
+    assert native.mrf_info(32, native.PREC_F32) is None
+    mi = native.mrf_info(32, native.PREC_BF16)
+    w = packing.pack_conv_weight_bf16(_rand(32, 32, 11, seed=1), mi.ck_bf16, mi.rows_per_block).to(DEV)
+    b = torch.zeros(32, device=DEV)
+    x = torch.zeros(1, 32, 64, device=DEV)
+    with pytest.raises(native.NativeError):          # reach 5 * (1+1 + 3+1 + 7+1) = 70 > 64
+        native.mrf_stage(x, torch.empty_like(x), [(11, [(w, b, w, b, d) for d in (1, 3, 7)])], slope=0.1)
+    with pytest.raises(native.NativeError):          # out on top of x
+        native.mrf_stage(x, x, [(11, [(w, b, w, b, 1)])], slope=0.1)

@@ -9,6 +9,7 @@
 #include "resblock_pair_bf16.hpp"
 #include "conv_split.hpp"
 #include "wn_layer.hpp"
+#include "mrf_stage.hpp"
 #include "api_internal.hpp"
 
 static thread_local char g_err[512] = "";
@@ -41,6 +42,7 @@ extern "C" size_t vk_sizeof_args(int which)
     case 1: return sizeof(vk_pair_args);
     case 2: return sizeof(vk_wn_args);
     case 3: return sizeof(vk_tile_info);
+    case 4: return sizeof(vk_mrf_args);
     default: return 0;
     }
 }
@@ -426,6 +428,64 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
     const size_t lds = (xs > as ? xs : as) * sizeof(float);
     int e = vk_launch_wn_layer(b_rep, a->last ? 1 : 0, vec, q, grid, lds, (hipStream_t)stream);
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_wn_layer: this combination is not built");
+    if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
+    return VK_OK;
+}
+
+extern "C" int vk_mrf_query(int channels, int precision, vk_tile_info* info)
+{
+    if (!info) return vk_fail(VK_E_ARG, "vk_mrf_query: null info");
+    if (precision != VK_PREC_BF16 || (channels != 32 && channels != 64))
+        return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_query: the fused stage is built for bf16 inputs at 32 and 64 channels");
+    info->ck = 0; info->ck_bf16 = 32; info->ck_split = 0;
+    info->rows_per_block = 32;
+    info->time_tile = VK_MRF_OUT;
+    info->a_rep = 1;
+    return VK_OK;
+}
+
+extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
+{
+    if (!a) return vk_fail(VK_E_ARG, "vk_mrf_stage: null argument block");
+    if (!a->x || !a->out) return vk_fail(VK_E_ARG, "vk_mrf_stage: null x / out pointer");
+    if (a->precision != VK_PREC_BF16) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for VK_PREC_BF16");
+    if (a->channels != 32 && a->channels != 64) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for 32 and 64 channels");
+    if (a->batch <= 0 || a->batch > 65535 || a->length <= 0) return vk_fail(VK_E_ARG, "vk_mrf_stage: bad batch or length");
+    if (a->n_blocks < 1 || a->n_blocks > VK_MRF_MAX_BLOCKS || a->n_pairs < 1 || a->n_pairs > VK_MRF_MAX_PAIRS)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: 1..4 resblocks of 1..4 pairs");
+    if (!(a->slope >= 0.0f && a->slope <= 1.0f)) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: slope must lie in [0, 1]");
+    if (a->x_cstride < 0 || a->out_cstride < 0 || a->x_bstride < 0 || a->out_bstride < 0)
+        return vk_fail(VK_E_ARG, "vk_mrf_stage: negative stride");
+    MrfDev q;
+    memset(&q, 0, sizeof(q));
+    q.a = *a;
+    for (int r = 0; r < a->n_blocks; ++r) {
+        const int k = a->taps[r];
+        if (k < 1 || !(k & 1)) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: taps must be odd");
+        int reach = 0;
+        for (int j = 0; j < a->n_pairs; ++j) {
+            if (a->dilation[r][j] < 1) return vk_fail(VK_E_ARG, "vk_mrf_stage: dilation < 1");
+            if (!a->w1[r][j] || !a->w2[r][j]) return vk_fail(VK_E_ARG, "vk_mrf_stage: null weight pointer");
+            if ((k - 1) / 2 * a->dilation[r][j] > VK_MRF_GUARD)
+                return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: (taps-1)/2 * dilation exceeds 32");
+            reach += (k - 1) / 2 * (a->dilation[r][j] + 1);
+        }
+        if (reach > VK_MRF_HALO) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: a resblock reaches further than 64 samples");
+        q.groups[r] = (a->channels / 32) * k * 2;
+    }
+    auto span = [&](int64_t cstride) -> int64_t { return ((int64_t)(a->channels - 1) * cstride + a->length) * 4; };
+    const int64_t xb = span(a->x_cstride), ob = span(a->out_cstride);
+    if (xb > 0x7fffffffLL || ob > 0x7fffffffLL)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: one batch item's view spans more than 2 GiB");
+    {   // other workgroups read halo columns of x for as long as the launch runs
+        const char* x0 = (const char*)a->x;   const char* x1 = x0 + (int64_t)(a->batch - 1) * a->x_bstride * 4 + xb;
+        const char* o0 = (const char*)a->out; const char* o1 = o0 + (int64_t)(a->batch - 1) * a->out_bstride * 4 + ob;
+        if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_mrf_stage: out overlaps x");
+    }
+    q.x_bytes = (unsigned)xb; q.out_bytes = (unsigned)ob;
+    dim3 grid((unsigned)((a->length + VK_MRF_OUT - 1) / VK_MRF_OUT), 1, (unsigned)a->batch);
+    int e = vk_launch_mrf_bf16(a->channels, q, grid, vk_mrf_lds_bytes(a->channels), (hipStream_t)stream);
+    if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: this channel count is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
     return VK_OK;
 }

@@ -1,0 +1,224 @@
+// One launch for a whole multi-receptive-field stage of the HiFi-GAN decoder
+// (/root/reference/module/model_component/decoder.py:119-125 around :46-61):
+//
+//   out = ( sum over resblocks r of  resblock_r(x) ) / n_blocks
+//   resblock_r:  for each pair j:  h = conv1_rj(lrelu(x_r));  x_r = conv2_rj(lrelu(h)) + x_r
+//
+// with bf16 matrix-core inputs and fp32 accumulation (the arithmetic of conv_bf16.hpp and
+// resblock_pair_bf16.hpp: activations are leaky-ReLU'd and rounded to bf16 where they enter a
+// matrix instruction; bias, residual chain and the sum over resblocks stay fp32).
+//
+// A workgroup owns every channel of a window of 384 time steps, of which the inner 256 are
+// outputs and 64 on each side are halo (a resblock's receptive half-width: 12 / 36 / 60 samples
+// for kernel sizes 3 / 7 / 11 with dilations 1, 3, 5).  Nothing but the stage input and the
+// stage output touches HBM:
+//   * the residual stream x_r lives in REGISTERS, in accumulator layout: a wave owns 32 channels
+//     of three adjacent 32-column tiles, so `x_r = conv2(...) + x_r` is a register add and the
+//     sum over the resblocks (kernel sizes) is accumulated in registers too;
+//   * what the convolutions read through the matrix cores - bf16(lrelu(x_r)) and bf16(lrelu(h)) -
+//     lives in two LDS images, channel-minor [column][channel] like conv_bf16.hpp, so a B fragment
+//     is one 16-byte read and a tap is a column offset; a wave writes its own three tiles after
+//     each convolution and reads its neighbours' columns as halo after a barrier;
+//   * weights stream from L2 in fragment order one tap ahead, and the first fragments of the next
+//     convolution are requested before the current one starts (a convolution of a 32-channel
+//     stage is only a few dozen matrix instructions per wave).
+// Columns outside [0, L) are forced to zero after every convolution (the zero padding each
+// reference conv sees); columns of the window that a later convolution cannot reach any more
+// hold don't-care values that never reach an output column.
+#pragma once
+#include "conv_bf16.hpp"
+#include "resblock_pair_bf16.hpp"
+
+constexpr int VK_MRF_WN     = 4;                            // waves along time
+constexpr int VK_MRF_NTW    = 3;                            // 32-column tiles per wave
+constexpr int VK_MRF_WIN    = 32 * VK_MRF_NTW * VK_MRF_WN;  // 384 columns per workgroup
+constexpr int VK_MRF_HALO   = 64;
+constexpr int VK_MRF_OUT    = VK_MRF_WIN - 2 * VK_MRF_HALO; // 256 output columns
+constexpr int VK_MRF_GUARD  = 32;                           // addressable columns on either side of an image
+
+struct MrfDev {
+    vk_mrf_args a;
+    unsigned x_bytes, out_bytes;    // byte spans of one batch item's views
+    int groups[VK_MRF_MAX_BLOCKS];  // 64-lane x 16-byte groups per 32-row tile of a conv of block r: chunks * taps * 2
+};
+
+constexpr size_t vk_mrf_lds_bytes(int channels)
+{
+    return (size_t)2 * (VK_MRF_WIN + 2 * VK_MRF_GUARD) * (channels * 2 + 16)
+         + (size_t)VK_MRF_MAX_BLOCKS * VK_MRF_MAX_PAIRS * 2 * channels * sizeof(float);
+}
+
+template <int WM>
+__global__ void __launch_bounds__(64 * WM * VK_MRF_WN, 2)
+mrf_stage_bf16_kernel(const MrfDev q)
+{
+    constexpr int WN  = VK_MRF_WN;
+    constexpr int NT  = VK_MRF_NTW;
+    constexpr int C   = 32 * WM;
+    constexpr int NCH = C / 32;                 // K-chunks of 32 channels (two matrix instructions per tap each)
+    constexpr int KS  = 2;
+    constexpr int PITCH = C * 2 + 16;           // bytes per column (odd multiple of 16: conflict-free 16-byte reads)
+    constexpr int IMG = (VK_MRF_WIN + 2 * VK_MRF_GUARD) * PITCH;
+
+    extern __shared__ __attribute__((aligned(16))) char lds8[];
+    char* img_a = lds8;                         // bf16(lrelu(x_r)): input of the dilated convs
+    char* img_h = lds8 + IMG;                   // bf16(lrelu(h)):   input of the plain convs
+    float* bias_tab = reinterpret_cast<float*>(lds8 + 2 * IMG);
+
+    const vk_mrf_args& p = q.a;
+    const int lane = threadIdx.x & 63;
+    const int w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm   = w % WM;
+    const int wn   = w / WM;
+    const int half = lane >> 5;
+    const int l31  = lane & 31;
+    const int b    = blockIdx.z;
+    const int t0   = blockIdx.x * VK_MRF_OUT;
+    const int L    = p.length;
+    const int col0 = wn * (32 * NT) + l31;      // this lane's window column in its first tile
+    const int tw   = t0 - VK_MRF_HALO + col0;   // ... and its time step
+
+    // every conv's bias, once, into LDS: entry ((r * n_pairs + j) * 2 + which) * C + channel
+    for (int i = threadIdx.x; i < p.n_blocks * p.n_pairs * 2 * C; i += 64 * WM * WN) {
+        const int conv = i / C, ch = i - conv * C;
+        const int rj = conv >> 1, r = rj / p.n_pairs, j = rj - r * p.n_pairs;
+        const float* bp = (conv & 1) ? p.bias2[r][j] : p.bias1[r][j];
+        bias_tab[i] = bp ? bp[ch] : 0.0f;
+    }
+
+    bool inside[NT];                            // this lane's column of tile n lies in [0, L)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) inside[n] = (tw + 32 * n >= 0) && (tw + 32 * n < L);
+
+    // weight fragments of the conv about to run (first tap), requested one conv ahead
+    auto wfrag = [&](const void* wp, int groups) {
+        return reinterpret_cast<const bf16x8*>(wp) + ((int64_t)wm * groups) * 64 + lane;
+    };
+    bf16x8 a_pre[KS];
+    {
+        const bf16x8* first = wfrag(p.w1[0][0], q.groups[0]);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) a_pre[k] = first[64 * k];
+    }
+
+    // accumulator-layout register r of a lane is channel 32*wm + (r & 3) + 8*(r >> 2) + 4*half;
+    // four consecutive registers are four consecutive channels: one 8-byte store into an image
+    auto put_image = [&](char* img, const f32x16 (&v)[NT], bool act_only_inside) {
+        char* dst = img + (VK_MRF_GUARD + col0) * PITCH + (wm * 32 + 4 * half) * 2;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    float v0 = vk_lrelu(v[n][4 * g + e], p.slope);
+                    float v1 = vk_lrelu(v[n][4 * g + e + 1], p.slope);
+                    if (act_only_inside) { v0 = inside[n] ? v0 : 0.0f; v1 = inside[n] ? v1 : 0.0f; }
+                    const f32x2 pr = {v0, v1};
+                    const bf16x2 c2 = __builtin_convertvector(pr, bf16x2);
+                    o[e] = c2[0]; o[e + 1] = c2[1];
+                }
+                *reinterpret_cast<bf16x4*>(dst + n * 32 * PITCH + g * 16) = o;
+            }
+    };
+
+    // one convolution of this wave's three tiles: bias, then every chunk's taps out of an image
+    f32x16 acc[1][NT];
+    bf16x8 a[KS][1];
+    const bf16x8* aptr[1];
+    auto conv = [&](const char* img, int conv_index, const void* wp, int groups, int taps, int dilation,
+                    const void* w_next, int groups_next) {
+        const float* bt = bias_tab + conv_index * C + wm * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bt[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[0][n][r] = bv;
+        }
+        aptr[0] = wfrag(wp, groups);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) a[k][0] = a_pre[k];
+        if (w_next != nullptr) {                                    // wave-uniform
+            const bf16x8* nx = wfrag(w_next, groups_next);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) a_pre[k] = nx[64 * k];
+        }
+        const int pad = ((taps - 1) >> 1) * dilation;
+        const char* base = img + (VK_MRF_GUARD + col0 - pad) * PITCH + half * 16;
+        for (int chunk = 0; chunk < NCH; ++chunk)
+            bf16_taps<1, NT, KS, PITCH>(acc, a, aptr, base + chunk * 64, taps, dilation * PITCH);
+    };
+
+    const __amdgpu_buffer_rsrc_t r_x = vk_rsrc(p.x + (int64_t)b * p.x_bstride, q.x_bytes);
+    f32x16 xr[NT], tot[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[n][r] = 0.0f;
+
+    for (int blk = 0; blk < p.n_blocks; ++blk) {
+        // the stage input, straight into accumulator layout (32 lanes = 128 contiguous bytes of a row;
+        // the row of a register differs between the two halves of the wave, hence a per-lane row term)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int t = tw + 32 * n;
+            const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2);                  // wave-uniform part
+                const int voff = 4 * (tc + 4 * half * (int)p.x_cstride);
+                const float v = vk_bld(r_x, voff, row * (int)p.x_cstride * 4);
+                xr[n][r] = inside[n] ? v : 0.0f;
+            }
+        }
+        put_image(img_a, xr, false);
+        __syncthreads();
+
+        const int taps = p.taps[blk];
+        for (int j = 0; j < p.n_pairs; ++j) {
+            const int ci = (blk * p.n_pairs + j) * 2;
+            // ---- h = conv1(lrelu(x_r)), dilated ----
+            conv(img_a, ci, p.w1[blk][j], q.groups[blk], taps, p.dilation[blk][j], p.w2[blk][j], q.groups[blk]);
+            put_image(img_h, acc[0], true);
+            __syncthreads();
+            // ---- x_r = conv2(lrelu(h)) + x_r ----
+            const bool last_pair = j + 1 == p.n_pairs;
+            const bool last_conv = last_pair && blk + 1 == p.n_blocks;
+            const void* wn1 = last_conv ? nullptr : (last_pair ? p.w1[blk + 1][0] : p.w1[blk][j + 1]);
+            const int gn1 = last_conv ? 0 : (last_pair ? q.groups[blk + 1] : q.groups[blk]);
+            conv(img_h, ci + 1, p.w2[blk][j], q.groups[blk], taps, 1, wn1, gn1);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xr[n][r] = inside[n] ? acc[0][n][r] + xr[n][r] : 0.0f;
+            if (!last_pair) {
+                put_image(img_a, xr, false);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[n][r] += xr[n][r];
+    }
+
+    // ---- out = sum / n_blocks for the window's output columns ----
+    const __amdgpu_buffer_rsrc_t r_out = vk_rsrc(p.out + (int64_t)b * p.out_bstride, q.out_bytes);
+    const float nb = (float)p.n_blocks;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int c = col0 + 32 * n;
+        const int t = tw + 32 * n;
+        if (c >= VK_MRF_HALO && c < VK_MRF_HALO + VK_MRF_OUT && t < L) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2);
+                vk_bst(tot[n][r] / nb, r_out, 4 * (t + 4 * half * (int)p.out_cstride), row * (int)p.out_cstride * 4);
+            }
+        }
+    }
+}
+
+// Returns hipSuccess / a HIP error, or -1 when there is no kernel for this channel count.
+int vk_launch_mrf_bf16(int channels, const MrfDev& q, dim3 grid, size_t lds, hipStream_t s);

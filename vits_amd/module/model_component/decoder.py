@@ -154,8 +154,42 @@ class DecoderPlan:
             self.ups.append((PackedConv(poly, up.bias, device, pad=1, row_order=None if order is None else order.to(device)),
                              s, wt.shape[1]))
         self.resblocks = [rb.plan(device) for rb in dec.resblocks]
+        self.stages = [self._fused_stage(dec, i, device) for i in range(dec.num_deconvs)]
         self.side_streams = None            # created on first use by a small-batch forward
         self.post_w = dec.conv1d_post.weight.detach().to(device)[0].contiguous()    # [C, taps]
+
+
+    @staticmethod
+    def _fused_stage(dec, stage, device):
+        """Weights of a whole multi-receptive-field stage packed for the one-launch kernel
+        (bf16 matrix inputs, 32 / 64 channels, equal dilation lists, reach <= 64 samples), or
+        None where the stage runs resblock by resblock.  VITS_AMD_MRF_FUSION=0 turns it off."""
+        from ...engine import precision
+        nrb = dec.num_resnet_blocks
+        rbs = [dec.resblocks[stage * nrb + j] for j in range(nrb)]
+        ch = rbs[0].channels
+        if os.environ.get("VITS_AMD_MRF_FUSION", "1") == "0" or precision() != native.PREC_BF16:
+            return None
+        mi = native.mrf_info(ch, native.PREC_BF16)
+        if mi is None or nrb > native.MRF_MAX_BLOCKS or any(len(rb.dilation) != len(rbs[0].dilation) for rb in rbs) \
+                or len(rbs[0].dilation) > native.MRF_MAX_PAIRS:
+            return None
+        for rb in rbs:
+            k = rb.kernel_size
+            if k % 2 == 0 or sum((k - 1) // 2 * (d + 1) for d in rb.dilation) > 64 \
+                    or any((k - 1) // 2 * d > 32 for d in rb.dilation):
+                return None
+        blocks = []
+        for rb in rbs:
+            pairs = []
+            for j, d in enumerate(rb.dilation):
+                c1, c2 = rb.convs1[j], rb.convs2[j]
+                pairs.append((packing.pack_conv_weight_bf16(c1.effective_weight().to(device), mi.ck_bf16, mi.rows_per_block),
+                              c1.bias.detach().to(device=device, dtype=torch.float32).contiguous(),
+                              packing.pack_conv_weight_bf16(c2.effective_weight().to(device), mi.ck_bf16, mi.rows_per_block),
+                              c2.bias.detach().to(device=device, dtype=torch.float32).contiguous(), d))
+            blocks.append((rb.kernel_size, pairs))
+        return blocks
 
 
 class Decoder(nn.Module):
@@ -257,6 +291,11 @@ class Decoder(nn.Module):
                           epilogue=native.EPI_UPSAMPLE, bias=up.bias, act_in=True, in_slope=LRELU_SLOPE,
                           up_stride=s)
             xs = torch.empty_like(xu)
+            if plan.stages[i] is not None:
+                # the whole stage in one launch: residual stream and the sum over kernel sizes in registers
+                native.mrf_stage(xu, xs, plan.stages[i], slope=LRELU_SLOPE)
+                x = xs
+                continue
             epis = [native.EPI_RESID] + [native.EPI_RESID_ACC] * (nrb - 2) + [native.EPI_RESID_AVG] if nrb > 1 \
                 else [native.EPI_RESID]
             if self._branches_concurrent(B, T) and nrb > 1:

@@ -85,6 +85,26 @@ class WnArgs(C.Structure):
     ]
 
 
+MRF_MAX_BLOCKS, MRF_MAX_PAIRS = 4, 4
+
+
+class MrfArgs(C.Structure):
+    """Mirror of ``vk_mrf_args``."""
+    _fields_ = [
+        ("x", _fp), ("x_bstride", C.c_int64), ("x_cstride", C.c_int64),
+        ("out", _fp), ("out_bstride", C.c_int64), ("out_cstride", C.c_int64),
+        ("batch", C.c_int32), ("channels", C.c_int32), ("length", C.c_int32),
+        ("n_blocks", C.c_int32), ("n_pairs", C.c_int32),
+        ("taps", C.c_int32 * MRF_MAX_BLOCKS),
+        ("dilation", (C.c_int32 * MRF_MAX_PAIRS) * MRF_MAX_BLOCKS),
+        ("w1", (_fp * MRF_MAX_PAIRS) * MRF_MAX_BLOCKS),
+        ("bias1", (_fp * MRF_MAX_PAIRS) * MRF_MAX_BLOCKS),
+        ("w2", (_fp * MRF_MAX_PAIRS) * MRF_MAX_BLOCKS),
+        ("bias2", (_fp * MRF_MAX_PAIRS) * MRF_MAX_BLOCKS),
+        ("slope", C.c_float), ("precision", C.c_int32),
+    ]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -123,13 +143,15 @@ def lib():
         L.vk_resblock_pair.argtypes = [C.POINTER(PairArgs), C.c_void_p]
         L.vk_wn_query.argtypes = [C.c_int, C.POINTER(TileInfo)]
         L.vk_wn_layer.argtypes = [C.POINTER(WnArgs), C.c_void_p]
+        L.vk_mrf_query.argtypes = [C.c_int, C.c_int, C.POINTER(TileInfo)]
+        L.vk_mrf_stage.argtypes = [C.POINTER(MrfArgs), C.c_void_p]
         L.vk_sizeof_args.argtypes = [C.c_int]
         L.vk_sizeof_args.restype = C.c_size_t
         want = header_abi_version()
         if L.vk_abi_version() != want:
             raise NativeError(f"{_lib_path}: ABI version {L.vk_abi_version()}, include/vits_amd.h declares {want}; "
                               "rebuild with `python -m vits_amd.build`")
-        for which, mirror in enumerate((ConvArgs, PairArgs, WnArgs, TileInfo)):
+        for which, mirror in enumerate((ConvArgs, PairArgs, WnArgs, TileInfo, MrfArgs)):
             if L.vk_sizeof_args(which) != C.sizeof(mirror):
                 raise NativeError(f"{mirror.__name__} is {C.sizeof(mirror)} bytes here, "
                                   f"{L.vk_sizeof_args(which)} in the library: native.py is out of step with the header")
@@ -309,6 +331,46 @@ def resblock_pair(x, w1, bias1, w2, bias2, out, *, taps, dilation, epilogue, slo
     nbytes = 4.0 * (x.numel() + out.numel() + (acc.numel() if acc is not None else 0))
     check(_timed(family, flops, nbytes, x.device, lambda: L.vk_resblock_pair(C.byref(a), sp), detail),
           "vk_resblock_pair")
+
+
+_mrf_cache = {}
+
+
+def mrf_info(channels: int, precision: int):
+    """Packing geometry of the fused multi-receptive-field stage kernel, or None if there is none
+    for this width and precision."""
+    key = (channels, precision)
+    if key not in _mrf_cache:
+        ti = TileInfo()
+        _mrf_cache[key] = ti if lib().vk_mrf_query(channels, precision, C.byref(ti)) == 0 else None
+    return _mrf_cache[key]
+
+
+def mrf_stage(x, out, blocks, *, slope):
+    """out = mean over resblocks of resblock(x) in one launch.  ``blocks``: per resblock
+    (taps, [(w1, bias1, w2, bias2, dilation) per pair]) with bf16 fragment-packed weights."""
+    assert x.is_cuda and x.dtype == torch.float32 and out.dtype == torch.float32
+    a = MrfArgs()
+    a.x, a.x_bstride, a.x_cstride = _view(x)
+    a.out, a.out_bstride, a.out_cstride = _view(out)
+    a.batch, a.channels, a.length = x.shape
+    a.n_blocks, a.n_pairs = len(blocks), len(blocks[0][1])
+    flops = 0.0
+    for r, (taps, pairs) in enumerate(blocks):
+        assert len(pairs) == a.n_pairs
+        a.taps[r] = taps
+        for j, (w1, b1, w2, b2, dil) in enumerate(pairs):
+            assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+            a.dilation[r][j] = dil
+            a.w1[r][j], a.w2[r][j] = w1.data_ptr(), w2.data_ptr()
+            a.bias1[r][j] = b1.data_ptr() if b1 is not None else None
+            a.bias2[r][j] = b2.data_ptr() if b2 is not None else None
+            flops += 4.0 * x.shape[0] * x.shape[2] * x.shape[1] * x.shape[1] * taps
+    a.slope, a.precision = slope, PREC_BF16
+    L, sp = lib(), stream_ptr(x.device)
+    check(_timed(f"mrf_stage_bf16[c{x.shape[1]}]", flops, 4.0 * (x.numel() + out.numel()), x.device,
+                 lambda: L.vk_mrf_stage(C.byref(a), sp), f"B{x.shape[0]} L{x.shape[2]} c{x.shape[1]}"),
+          "vk_mrf_stage")
 
 
 _wn_cache = {}
