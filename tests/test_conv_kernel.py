@@ -232,7 +232,7 @@ def test_fused_pair_rejects_bad_arguments():
     with pytest.raises(native.NativeError):      # halo too long
         native.resblock_pair(x, wp, b, wp, b, torch.empty_like(x), taps=3, dilation=30,
                              epilogue=native.EPI_RESID, slope=0.1)
-    assert native.pair_info(128) is None and native.pair_info(256, native.PREC_BF16) is None
+    assert native.pair_info(128) is None and native.pair_info(512, native.PREC_BF16) is None
     x128 = torch.zeros(1, 128, 64, device=DEV)
     with pytest.raises(native.NativeError):      # width without a fused kernel
         native.resblock_pair(x128, wp, b, wp, b, torch.empty_like(x128), taps=3, dilation=1,
@@ -319,6 +319,8 @@ def test_bf16_gate_epilogue():
     (64, 3, 3, 3, 1200),
     (128, 7, 1, 1, 244),         # exactly one 128-channel workgroup
     (128, 11, 5, 2, 777),
+    (256, 3, 1, 1, 245),         # one column into the second 256-channel workgroup
+    (256, 11, 5, 2, 600),
 ])
 def test_bf16_fused_resblock_pair(ch, k, dil, B, L):
     x = _rand(B, ch, L, seed=91)
@@ -492,10 +494,10 @@ def _mrf_reference(x, blocks, slope=0.1, rnd=None):
 @pytest.mark.parametrize("ch,B,L,kernels,dils", [
     (32, 2, 1, (3, 7, 11), (1, 3, 5)),
     (32, 2, 37, (3, 7, 11), (1, 3, 5)),
-    (32, 3, 256, (3, 7, 11), (1, 3, 5)),       # exactly one workgroup of outputs
-    (32, 1, 257, (3, 7, 11), (1, 3, 5)),       # one column into the second workgroup
+    (32, 3, 384, (3, 7, 11), (1, 3, 5)),       # exactly one workgroup of outputs
+    (32, 1, 385, (3, 7, 11), (1, 3, 5)),       # one column into the second workgroup
     (32, 2, 1500, (3, 7, 11), (1, 3, 5)),
-    (64, 2, 463, (3, 7, 11), (1, 3, 5)),
+    (64, 2, 385, (3, 7, 11), (1, 3, 5)),
     (64, 1, 1031, (3, 7, 11), (1, 3, 5)),
     (64, 2, 300, (5, 3), (2, 1)),              # two resblocks of two pairs
     (32, 1, 700, (11,), (1, 3, 5)),            # a single resblock: the mean is the resblock

@@ -263,6 +263,7 @@ static const PairGeomBf16* pair_geom_bf16(int channels)
     if (channels == 32) return &kPairBf16_32;
     if (channels == 64) return &kPairBf16_64;
     if (channels == 128) return &kPairBf16_128;
+    if (channels == 256) return &kPairBf16_256;
     return nullptr;
 }
 
@@ -435,11 +436,11 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
 extern "C" int vk_mrf_query(int channels, int precision, vk_tile_info* info)
 {
     if (!info) return vk_fail(VK_E_ARG, "vk_mrf_query: null info");
-    if (precision != VK_PREC_BF16 || (channels != 32 && channels != 64))
-        return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_query: the fused stage is built for bf16 inputs at 32 and 64 channels");
+    const MrfGeom* G = precision == VK_PREC_BF16 ? vk_mrf_geom(channels) : nullptr;
+    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_query: the fused stage is built for bf16 inputs at 32 and 64 channels");
     info->ck = 0; info->ck_bf16 = 32; info->ck_split = 0;
     info->rows_per_block = 32;
-    info->time_tile = VK_MRF_OUT;
+    info->time_tile = vk_mrf_window(*G) - 2 * VK_MRF_HALO;
     info->a_rep = 1;
     return VK_OK;
 }
@@ -449,7 +450,8 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
     if (!a) return vk_fail(VK_E_ARG, "vk_mrf_stage: null argument block");
     if (!a->x || !a->out) return vk_fail(VK_E_ARG, "vk_mrf_stage: null x / out pointer");
     if (a->precision != VK_PREC_BF16) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for VK_PREC_BF16");
-    if (a->channels != 32 && a->channels != 64) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for 32 and 64 channels");
+    const MrfGeom* G = vk_mrf_geom(a->channels);
+    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for 32 and 64 channels");
     if (a->batch <= 0 || a->batch > 65535 || a->length <= 0) return vk_fail(VK_E_ARG, "vk_mrf_stage: bad batch or length");
     if (a->n_blocks < 1 || a->n_blocks > VK_MRF_MAX_BLOCKS || a->n_pairs < 1 || a->n_pairs > VK_MRF_MAX_PAIRS)
         return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: 1..4 resblocks of 1..4 pairs");
@@ -483,8 +485,9 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
         if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_mrf_stage: out overlaps x");
     }
     q.x_bytes = (unsigned)xb; q.out_bytes = (unsigned)ob;
-    dim3 grid((unsigned)((a->length + VK_MRF_OUT - 1) / VK_MRF_OUT), 1, (unsigned)a->batch);
-    int e = vk_launch_mrf_bf16(a->channels, q, grid, vk_mrf_lds_bytes(a->channels), (hipStream_t)stream);
+    const int out_cols = vk_mrf_window(*G) - 2 * VK_MRF_HALO;
+    dim3 grid((unsigned)((a->length + out_cols - 1) / out_cols), 1, (unsigned)a->batch);
+    int e = vk_launch_mrf_bf16(a->channels, q, grid, vk_mrf_lds_bytes(*G), (hipStream_t)stream);
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: this channel count is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
     return VK_OK;

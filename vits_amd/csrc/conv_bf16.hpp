@@ -86,11 +86,33 @@ struct Bf16Stager {
     }
 };
 
-// The k-loop over one resident chunk (KS matrix instructions per tap): weights fetched one tap
+// Taps of weight fragments in flight ahead of the matrix instructions that consume them.  A tap
+// of a 32-channel chunk is only 2 * A_REP * B_REP matrix instructions (200-260 cycles), less than
+// an L2 hit takes on a busy chip, so fragments are requested two taps ahead.
+#ifndef VK_BF16_PF
+#define VK_BF16_PF 2
+#endif
+constexpr int VK_PF = VK_BF16_PF;
+
+// a[i] = fragments of tap i of the stream `aptr` points into (i < VK_PF)
+template <int KS, int A_REP>
+__device__ __forceinline__ void bf16_wload(bf16x8 (&a)[VK_PF][KS][A_REP], const bf16x8* (&aptr)[A_REP])
+{
+#pragma unroll
+    for (int i = 0; i < VK_PF; ++i)
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m) a[i][k][m] = aptr[m][64 * (KS * i + k)];
+}
+
+// The k-loop over one resident chunk (KS matrix instructions per tap): weights fetched VK_PF taps
 // ahead, B fragments of the next k-step read before the current k-step's MFMAs are issued.
-// `base` is this lane's fragment address for tap 0 / k-step 0 / column tile 0.
+// `base` is this lane's fragment address for tap 0 / k-step 0 / column tile 0.  The weight stream
+// runs on linearly past the chunk (next chunk, next row tile or the zero groups that end a packed
+// tensor), so a[] arrives holding the current tap and leaves holding the next chunk's first.
 template <int A_REP, int B_REP, int KS, int PITCH>
-__device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&a)[KS][A_REP],
+__device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&a)[VK_PF][KS][A_REP],
                                           const bf16x8* (&aptr)[A_REP], const char* base, int taps, int tap_step)
 {
     const char* bt = base;
@@ -104,7 +126,7 @@ __device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
-            for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = aptr[m][64 * (KS + k)];
+            for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = aptr[m][64 * (KS * VK_PF + k)];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             bf16x8 bn[B_REP];
@@ -116,7 +138,7 @@ __device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&
             for (int m = 0; m < A_REP; ++m)
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k][m], bf[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][k][m], bf[n], acc[m][n], 0, 0, 0);
 #pragma unroll
             for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
         }
@@ -126,7 +148,11 @@ __device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
-            for (int m = 0; m < A_REP; ++m) a[k][m] = a_nxt[k][m];
+            for (int m = 0; m < A_REP; ++m) {
+#pragma unroll
+                for (int i = 0; i + 1 < VK_PF; ++i) a[i][k][m] = a[i + 1][k][m];
+                a[VK_PF - 1][k][m] = a_nxt[k][m];
+            }
     }
 }
 
@@ -177,11 +203,8 @@ conv_bf16_kernel(const ConvDev d)
 #pragma unroll
     for (int m = 0; m < A_REP; ++m)
         aptr[m] = reinterpret_cast<const bf16x8*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
-    bf16x8 a[KS][A_REP];
-#pragma unroll
-    for (int k = 0; k < KS; ++k)
-#pragma unroll
-        for (int m = 0; m < A_REP; ++m) a[k][m] = aptr[m][64 * k];
+    bf16x8 a[VK_PF][KS][A_REP];
+    bf16_wload<KS, A_REP>(a, aptr);
 
     f32x16 acc[A_REP][B_REP];
     {

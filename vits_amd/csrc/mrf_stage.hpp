@@ -8,20 +8,23 @@
 // resblock_pair_bf16.hpp: activations are leaky-ReLU'd and rounded to bf16 where they enter a
 // matrix instruction; bias, residual chain and the sum over resblocks stay fp32).
 //
-// A workgroup owns every channel of a window of 384 time steps, of which the inner 256 are
-// outputs and 64 on each side are halo (a resblock's receptive half-width: 12 / 36 / 60 samples
-// for kernel sizes 3 / 7 / 11 with dilations 1, 3, 5).  Nothing but the stage input and the
-// stage output touches HBM:
+// A workgroup owns every channel of a window of W = 32 * NT * WN time steps (WN waves along time,
+// NT adjacent 32-column tiles per wave), of which the inner W - 128 are outputs and 64 on each
+// side are halo (a resblock's receptive half-width: 12 / 36 / 60 samples for kernel sizes
+// 3 / 7 / 11 with dilations 1, 3, 5).  Nothing but the stage input and the stage output touches HBM:
 //   * the residual stream x_r lives in REGISTERS, in accumulator layout: a wave owns 32 channels
-//     of three adjacent 32-column tiles, so `x_r = conv2(...) + x_r` is a register add and the
-//     sum over the resblocks (kernel sizes) is accumulated in registers too;
+//     of its NT tiles, so `x_r = conv2(...) + x_r` is a register add and the sum over the
+//     resblocks (kernel sizes) is accumulated in registers too;
 //   * what the convolutions read through the matrix cores - bf16(lrelu(x_r)) and bf16(lrelu(h)) -
-//     lives in two LDS images, channel-minor [column][channel] like conv_bf16.hpp, so a B fragment
-//     is one 16-byte read and a tap is a column offset; a wave writes its own three tiles after
-//     each convolution and reads its neighbours' columns as halo after a barrier;
-//   * weights stream from L2 in fragment order one tap ahead, and the first fragments of the next
-//     convolution are requested before the current one starts (a convolution of a 32-channel
-//     stage is only a few dozen matrix instructions per wave).
+//     lives in LDS, channel-minor [column][channel] like conv_bf16.hpp, so a B fragment is one
+//     16-byte read and a tap is a column offset; a wave writes its own tiles after each
+//     convolution and reads its neighbours' columns as halo after a barrier.  With two images
+//     (TWO) a convolution reads one and its result goes to the other: one barrier per
+//     convolution.  With one image the result replaces what was read (a second barrier in
+//     between) and the window can be twice as wide for the same LDS;
+//   * weights stream from L2 in fragment order VK_PF taps ahead, and the first fragments of the
+//     next convolution are requested before the current one starts (a convolution of a
+//     32-channel stage is only a few dozen matrix instructions per wave).
 // Columns outside [0, L) are forced to zero after every convolution (the zero padding each
 // reference conv sees); columns of the window that a later convolution cannot reach any more
 // hold don't-care values that never reach an output column.
@@ -29,12 +32,18 @@
 #include "conv_bf16.hpp"
 #include "resblock_pair_bf16.hpp"
 
-constexpr int VK_MRF_WN     = 4;                            // waves along time
-constexpr int VK_MRF_NTW    = 3;                            // 32-column tiles per wave
-constexpr int VK_MRF_WIN    = 32 * VK_MRF_NTW * VK_MRF_WN;  // 384 columns per workgroup
 constexpr int VK_MRF_HALO   = 64;
-constexpr int VK_MRF_OUT    = VK_MRF_WIN - 2 * VK_MRF_HALO; // 256 output columns
 constexpr int VK_MRF_GUARD  = 32;                           // addressable columns on either side of an image
+
+// geometry by channel count: waves along channels (32 each) x waves along time, tiles per wave
+struct MrfGeom { int wm, wn, nt, two; };
+static constexpr MrfGeom kMrf32 = {1, 4, 4, 0};             // 512-column window, 4 waves, one image (46 KB)
+static constexpr MrfGeom kMrf64 = {2, 4, 4, 0};             // 512-column window, 8 waves, one image (83 KB)
+static inline const MrfGeom* vk_mrf_geom(int channels)
+{
+    return channels == 32 ? &kMrf32 : channels == 64 ? &kMrf64 : nullptr;
+}
+static inline int vk_mrf_window(const MrfGeom& g) { return 32 * g.nt * g.wn; }
 
 struct MrfDev {
     vk_mrf_args a;
@@ -42,28 +51,29 @@ struct MrfDev {
     int groups[VK_MRF_MAX_BLOCKS];  // 64-lane x 16-byte groups per 32-row tile of a conv of block r: chunks * taps * 2
 };
 
-constexpr size_t vk_mrf_lds_bytes(int channels)
+static inline size_t vk_mrf_lds_bytes(const MrfGeom& g)
 {
-    return (size_t)2 * (VK_MRF_WIN + 2 * VK_MRF_GUARD) * (channels * 2 + 16)
+    const int channels = 32 * g.wm;
+    return (size_t)(g.two ? 2 : 1) * (vk_mrf_window(g) + 2 * VK_MRF_GUARD) * (channels * 2 + 16)
          + (size_t)VK_MRF_MAX_BLOCKS * VK_MRF_MAX_PAIRS * 2 * channels * sizeof(float);
 }
 
-template <int WM>
-__global__ void __launch_bounds__(64 * WM * VK_MRF_WN, 2)
+template <int WM, int WN, int NT, bool TWO>
+__global__ void __launch_bounds__(64 * WM * WN, 2)
 mrf_stage_bf16_kernel(const MrfDev q)
 {
-    constexpr int WN  = VK_MRF_WN;
-    constexpr int NT  = VK_MRF_NTW;
+    constexpr int WIN = 32 * NT * WN;           // window columns
+    constexpr int OUT = WIN - 2 * VK_MRF_HALO;  // output columns
     constexpr int C   = 32 * WM;
     constexpr int NCH = C / 32;                 // K-chunks of 32 channels (two matrix instructions per tap each)
     constexpr int KS  = 2;
     constexpr int PITCH = C * 2 + 16;           // bytes per column (odd multiple of 16: conflict-free 16-byte reads)
-    constexpr int IMG = (VK_MRF_WIN + 2 * VK_MRF_GUARD) * PITCH;
+    constexpr int IMG = (WIN + 2 * VK_MRF_GUARD) * PITCH;
 
     extern __shared__ __attribute__((aligned(16))) char lds8[];
     char* img_a = lds8;                         // bf16(lrelu(x_r)): input of the dilated convs
-    char* img_h = lds8 + IMG;                   // bf16(lrelu(h)):   input of the plain convs
-    float* bias_tab = reinterpret_cast<float*>(lds8 + 2 * IMG);
+    char* img_h = TWO ? lds8 + IMG : lds8;      // bf16(lrelu(h)):   input of the plain convs
+    float* bias_tab = reinterpret_cast<float*>(lds8 + (TWO ? 2 : 1) * IMG);
 
     const vk_mrf_args& p = q.a;
     const int lane = threadIdx.x & 63;
@@ -73,7 +83,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
     const int half = lane >> 5;
     const int l31  = lane & 31;
     const int b    = blockIdx.z;
-    const int t0   = blockIdx.x * VK_MRF_OUT;
+    const int t0   = blockIdx.x * OUT;
     const int L    = p.length;
     const int col0 = wn * (32 * NT) + l31;      // this lane's window column in its first tile
     const int tw   = t0 - VK_MRF_HALO + col0;   // ... and its time step
@@ -94,11 +104,10 @@ mrf_stage_bf16_kernel(const MrfDev q)
     auto wfrag = [&](const void* wp, int groups) {
         return reinterpret_cast<const bf16x8*>(wp) + ((int64_t)wm * groups) * 64 + lane;
     };
-    bf16x8 a_pre[KS];
+    bf16x8 a_pre[VK_PF][KS][1];
     {
-        const bf16x8* first = wfrag(p.w1[0][0], q.groups[0]);
-#pragma unroll
-        for (int k = 0; k < KS; ++k) a_pre[k] = first[64 * k];
+        const bf16x8* first[1] = {wfrag(p.w1[0][0], q.groups[0])};
+        bf16_wload<KS, 1>(a_pre, first);
     }
 
     // accumulator-layout register r of a lane is channel 32*wm + (r & 3) + 8*(r >> 2) + 4*half;
@@ -125,7 +134,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
 
     // one convolution of this wave's three tiles: bias, then every chunk's taps out of an image
     f32x16 acc[1][NT];
-    bf16x8 a[KS][1];
+    bf16x8 a[VK_PF][KS][1];
     const bf16x8* aptr[1];
     auto conv = [&](const char* img, int conv_index, const void* wp, int groups, int taps, int dilation,
                     const void* w_next, int groups_next) {
@@ -138,11 +147,12 @@ mrf_stage_bf16_kernel(const MrfDev q)
         }
         aptr[0] = wfrag(wp, groups);
 #pragma unroll
-        for (int k = 0; k < KS; ++k) a[k][0] = a_pre[k];
-        if (w_next != nullptr) {                                    // wave-uniform
-            const bf16x8* nx = wfrag(w_next, groups_next);
+        for (int i = 0; i < VK_PF; ++i)
 #pragma unroll
-            for (int k = 0; k < KS; ++k) a_pre[k] = nx[64 * k];
+            for (int k = 0; k < KS; ++k) a[i][k][0] = a_pre[i][k][0];
+        if (w_next != nullptr) {                                    // wave-uniform
+            const bf16x8* nx[1] = {wfrag(w_next, groups_next)};
+            bf16_wload<KS, 1>(a_pre, nx);
         }
         const int pad = ((taps - 1) >> 1) * dilation;
         const char* base = img + (VK_MRF_GUARD + col0 - pad) * PITCH + half * 16;
@@ -180,6 +190,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
             const int ci = (blk * p.n_pairs + j) * 2;
             // ---- h = conv1(lrelu(x_r)), dilated ----
             conv(img_a, ci, p.w1[blk][j], q.groups[blk], taps, p.dilation[blk][j], p.w2[blk][j], q.groups[blk]);
+            if (!TWO) __syncthreads();          // every wave has read what the next lines overwrite
             put_image(img_h, acc[0], true);
             __syncthreads();
             // ---- x_r = conv2(lrelu(h)) + x_r ----
@@ -193,6 +204,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) xr[n][r] = inside[n] ? acc[0][n][r] + xr[n][r] : 0.0f;
             if (!last_pair) {
+                if (!TWO) __syncthreads();
                 put_image(img_a, xr, false);
                 __syncthreads();
             }
@@ -201,6 +213,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tot[n][r] += xr[n][r];
+        if (!TWO && blk + 1 < p.n_blocks) __syncthreads();     // the next resblock's input replaces h
     }
 
     // ---- out = sum / n_blocks for the window's output columns ----
@@ -210,7 +223,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
     for (int n = 0; n < NT; ++n) {
         const int c = col0 + 32 * n;
         const int t = tw + 32 * n;
-        if (c >= VK_MRF_HALO && c < VK_MRF_HALO + VK_MRF_OUT && t < L) {
+        if (c >= VK_MRF_HALO && c < VK_MRF_HALO + OUT && t < L) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + (r & 3) + 8 * (r >> 2);

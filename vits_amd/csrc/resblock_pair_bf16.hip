@@ -20,5 +20,6 @@ int vk_launch_pair_bf16(int channels, int epi, const PairDev& q, dim3 grid, size
     VK_PAIR16_ALL(kPairBf16_32, 32)
     VK_PAIR16_ALL(kPairBf16_64, 64)
     VK_PAIR16_ALL(kPairBf16_128, 128)
+    VK_PAIR16_ALL(kPairBf16_256, 256)
     return -1;
 }

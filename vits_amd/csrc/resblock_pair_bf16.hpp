@@ -57,11 +57,8 @@ resblock_pair_bf16_kernel(const PairDev q)
 #pragma unroll
     for (int m = 0; m < A_REP; ++m)
         aptr[m] = reinterpret_cast<const bf16x8*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
-    bf16x8 a[KS][A_REP];
-#pragma unroll
-    for (int k = 0; k < KS; ++k)
-#pragma unroll
-        for (int m = 0; m < A_REP; ++m) a[k][m] = aptr[m][64 * k];
+    bf16x8 a[VK_PF][KS][A_REP];
+    bf16_wload<KS, A_REP>(a, aptr);
 
     f32x16 acc[A_REP][B_REP];
 #pragma unroll
@@ -88,10 +85,7 @@ resblock_pair_bf16_kernel(const PairDev q)
 #pragma unroll
     for (int m = 0; m < A_REP; ++m)
         aptr[m] = reinterpret_cast<const bf16x8*>(q.w2) + ((int64_t)(mt0 + m) * q.groups2) * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < KS; ++k)
-#pragma unroll
-        for (int m = 0; m < A_REP; ++m) a[k][m] = aptr[m][64 * k];
+    bf16_wload<KS, A_REP>(a, aptr);
 
     __syncthreads();                    // every wave is done reading the x tile
     {
@@ -145,7 +139,8 @@ resblock_pair_bf16_kernel(const PairDev q)
 struct PairGeomBf16 { int a_rep, b_rep, wm, wn; };
 static constexpr PairGeomBf16 kPairBf16_32  = {1, 4, 1, 4};     // 512-column window, 4 waves
 static constexpr PairGeomBf16 kPairBf16_64  = {1, 4, 2, 2};     // 256-column window, 4 waves
-static constexpr PairGeomBf16 kPairBf16_128 = {2, 2, 2, 2};     // 128-column window, 4 waves of 64 x 64
+static constexpr PairGeomBf16 kPairBf16_128 = {2, 4, 2, 2};     // 256-column window, 4 waves of 64 x 128 (8-wave splits measured slower)
+static constexpr PairGeomBf16 kPairBf16_256 = {2, 4, 4, 2};     // 256-column window, 8 waves of 64 x 128 (h tile 142 KB)
 
 // LDS bytes of a workgroup: the larger of the x staging buffers and the h tile (+ the columns
 // the second conv's invalid outputs read past the window)

@@ -226,16 +226,22 @@ class Decoder(nn.Module):
         self._plans = PlanCache(self, lambda dev: DecoderPlan(self, dev))
 
     # The resblocks of a stage are independent until their last convolution adds into the stage
-    # output.  With few utterances in flight one convolution does not fill 256 CUs, so each
-    # resblock then runs on a stream of its own; the last launches are chained by events in the
-    # reference's summation order (decoder.py:119-125), which keeps the result bit-identical.
-    concurrent_branch_frames = 2048         # use branch streams when batch * frames is at most this
+    # output, so each can run on a stream of its own; the last launches are chained by events in
+    # the reference's summation order (decoder.py:119-125), which keeps the result bit-identical.
+    # Used (a) with few utterances in flight, where one convolution does not fill 256 CUs, and
+    # (b) with bf16 matrix inputs at any size: there the short-kernel launches wait on memory and
+    # the long-kernel ones on the matrix cores, and workgroups of both kinds sharing a CU is
+    # worth 4 % of the batch-16 step.  The fp32 modes stay serial at large sizes (+2 % only, and
+    # per-launch device times stay attributable to one kernel).
+    concurrent_branch_frames = 2048         # fp32: use branch streams when batch * frames is at most this
 
     def _branches_concurrent(self, batch, frames):
+        from ...engine import precision
         mode = os.environ.get("VITS_AMD_BRANCH_STREAMS", "auto")
         if mode in ("0", "off"):
             return False
-        return mode in ("1", "on") or batch * frames <= self.concurrent_branch_frames
+        return (mode in ("1", "on") or batch * frames <= self.concurrent_branch_frames
+                or precision() == native.PREC_BF16)
 
     def _run_branches_concurrently(self, plan, stage, xu, xs, epis):
         nrb = self.num_resnet_blocks
