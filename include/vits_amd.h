@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 4
+#define VK_ABI_VERSION 5
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -48,6 +48,7 @@ typedef struct {
     int32_t a_rep;         /* consecutive 32-row tiles owned by one wavefront         */
     int32_t ck_bf16;       /* K-chunk of the bf16-input kernels (VK_PREC_BF16)         */
     int32_t ck_split;      /* K-chunk of the sliced-fp32 kernels (VK_PREC_F32_SPLIT)   */
+    int32_t max_blocks;    /* vk_mrf_query: resblocks one launch can sum; 0 elsewhere  */
 } vk_tile_info;
 
 /* Matrix-core input precision (vk_conv_args.precision).  Activations, bias, residuals and
@@ -195,10 +196,13 @@ int vk_wn_layer(const vk_wn_args* a, void* stream);
  * "same" padded.  The residual stream and the sum over the resblocks (kernel sizes) stay in
  * registers, the activated conv inputs in LDS; only x is read and out written.  Built for
  * VK_PREC_BF16 (bf16 matrix-core inputs, fp32 accumulation) and the channel widths
- * vk_mrf_query accepts; the receptive half-width of every resblock,
- * sum_j (taps[r]-1)/2 * (dilation[r][j] + 1), must not exceed 64.  Weights are packed like
- * vk_resblock_pair's for VK_PREC_BF16 (vk_mrf_query reports ck_bf16 and rows_per_block).
- * `out` must not overlap `x`.                                                          */
+ * vk_mrf_query accepts: 32 and 64 channels take up to VK_MRF_MAX_BLOCKS resblocks per launch,
+ * 128 and 256 channels one (vk_tile_info.max_blocks; a single resblock is its own mean, so
+ * out = resblock(x): the three pairs of a resblock chained without touching HBM).  The
+ * receptive half-width of every resblock, sum_j (taps[r]-1)/2 * (dilation[r][j] + 1), must not
+ * exceed 64; a workgroup recomputes that many columns on either side of its outputs, so the
+ * launch pays off for short kernels.  Weights are packed like vk_resblock_pair's for
+ * VK_PREC_BF16 (vk_mrf_query reports ck_bf16 and rows_per_block).  `out` must not overlap `x`. */
 #define VK_MRF_MAX_BLOCKS 4
 #define VK_MRF_MAX_PAIRS  4
 typedef struct {

@@ -503,6 +503,10 @@ def _mrf_reference(x, blocks, slope=0.1, rnd=None):
     (32, 1, 700, (11,), (1, 3, 5)),            # a single resblock: the mean is the resblock
     (32, 2, 900, (3, 7, 11), (5,)),            # one pair per resblock: no chain for a rounding flip to travel down
     (64, 2, 900, (11, 7, 3), (1,)),
+    (128, 2, 500, (3,), (1, 3, 5)),            # 128 channels: one resblock per launch
+    (128, 1, 233, (3,), (1, 3, 5)),            # ... 232 output columns per workgroup at reach 12
+    (128, 1, 300, (7,), (1, 3, 5)),
+    (256, 2, 209, (3,), (1, 3, 5)),            # 104 output columns per workgroup
 ])
 def test_bf16_fused_mrf_stage(ch, B, L, kernels, dils):
     mi = native.mrf_info(ch, native.PREC_BF16)
@@ -545,8 +549,9 @@ def test_bf16_fused_mrf_stage(ch, B, L, kernels, dils):
 
 
 def test_fused_mrf_stage_rejects_bad_arguments():
-    assert native.mrf_info(128, native.PREC_BF16) is None
+    assert native.mrf_info(512, native.PREC_BF16) is None
     assert native.mrf_info(32, native.PREC_F32) is None
+    assert native.mrf_info(32, native.PREC_BF16).max_blocks == 4 and native.mrf_info(128, native.PREC_BF16).max_blocks == 1
     mi = native.mrf_info(32, native.PREC_BF16)
     w = packing.pack_conv_weight_bf16(_rand(32, 32, 11, seed=1), mi.ck_bf16, mi.rows_per_block).to(DEV)
     b = torch.zeros(32, device=DEV)
@@ -555,3 +560,9 @@ def test_fused_mrf_stage_rejects_bad_arguments():
         native.mrf_stage(x, torch.empty_like(x), [(11, [(w, b, w, b, d) for d in (1, 3, 7)])], slope=0.1)
     with pytest.raises(native.NativeError):          # out on top of x
         native.mrf_stage(x, x, [(11, [(w, b, w, b, 1)])], slope=0.1)
+    m8 = native.mrf_info(128, native.PREC_BF16)
+    w8 = packing.pack_conv_weight_bf16(_rand(128, 128, 3, seed=2), m8.ck_bf16, m8.rows_per_block).to(DEV)
+    b8 = torch.zeros(128, device=DEV)
+    x8 = torch.zeros(1, 128, 64, device=DEV)
+    with pytest.raises(native.NativeError):          # two resblocks in one launch at 128 channels
+        native.mrf_stage(x8, torch.empty_like(x8), [(3, [(w8, b8, w8, b8, 1)])] * 2, slope=0.1)

@@ -57,6 +57,7 @@ extern "C" int vk_tile_query(int tile, vk_tile_info* info)
     info->a_rep = G.a_rep;
     info->ck_bf16 = kBf16Ck[tile];
     info->ck_split = VK_SPLIT_CK;
+    info->max_blocks = 0;
     return VK_OK;
 }
 
@@ -273,7 +274,7 @@ extern "C" int vk_pair_query(int channels, int precision, vk_tile_info* info)
     if (precision == VK_PREC_BF16) {
         const PairGeomBf16* G = pair_geom_bf16(channels);
         if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_pair_query: no fused bf16 kernel for this channel count");
-        info->ck = 0; info->ck_bf16 = 32; info->ck_split = 0;
+        info->ck = 0; info->ck_bf16 = 32; info->ck_split = 0; info->max_blocks = 0;
         info->rows_per_block = 32 * G->a_rep * G->wm;
         info->time_tile = 32 * G->b_rep * G->wn - VK_PAIR_OVERLAP;
         info->a_rep = G->a_rep;
@@ -287,6 +288,7 @@ extern "C" int vk_pair_query(int channels, int precision, vk_tile_info* info)
     info->a_rep = 1;
     info->ck_bf16 = 0;
     info->ck_split = 0;
+    info->max_blocks = 0;
     return VK_OK;
 }
 
@@ -369,6 +371,7 @@ extern "C" int vk_wn_query(int hidden, vk_tile_info* info)
     info->a_rep = 2;
     info->ck_bf16 = 0;
     info->ck_split = 0;
+    info->max_blocks = 0;
     return VK_OK;
 }
 
@@ -437,11 +440,12 @@ extern "C" int vk_mrf_query(int channels, int precision, vk_tile_info* info)
 {
     if (!info) return vk_fail(VK_E_ARG, "vk_mrf_query: null info");
     const MrfGeom* G = precision == VK_PREC_BF16 ? vk_mrf_geom(channels) : nullptr;
-    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_query: the fused stage is built for bf16 inputs at 32 and 64 channels");
+    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_query: the fused stage is built for bf16 inputs at 32, 64, 128 and 256 channels");
     info->ck = 0; info->ck_bf16 = 32; info->ck_split = 0;
     info->rows_per_block = 32;
-    info->time_tile = vk_mrf_window(*G) - 2 * VK_MRF_HALO;
+    info->time_tile = vk_mrf_window(*G) - 2 * VK_MRF_HALO;       // at least this many output columns per workgroup
     info->a_rep = 1;
+    info->max_blocks = G->sum ? VK_MRF_MAX_BLOCKS : 1;
     return VK_OK;
 }
 
@@ -451,16 +455,17 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
     if (!a->x || !a->out) return vk_fail(VK_E_ARG, "vk_mrf_stage: null x / out pointer");
     if (a->precision != VK_PREC_BF16) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for VK_PREC_BF16");
     const MrfGeom* G = vk_mrf_geom(a->channels);
-    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for 32 and 64 channels");
+    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for 32, 64, 128 and 256 channels");
     if (a->batch <= 0 || a->batch > 65535 || a->length <= 0) return vk_fail(VK_E_ARG, "vk_mrf_stage: bad batch or length");
-    if (a->n_blocks < 1 || a->n_blocks > VK_MRF_MAX_BLOCKS || a->n_pairs < 1 || a->n_pairs > VK_MRF_MAX_PAIRS)
-        return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: 1..4 resblocks of 1..4 pairs");
+    if (a->n_blocks < 1 || a->n_blocks > (G->sum ? VK_MRF_MAX_BLOCKS : 1) || a->n_pairs < 1 || a->n_pairs > VK_MRF_MAX_PAIRS)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: 1..4 resblocks (one at 128 / 256 channels) of 1..4 pairs");
     if (!(a->slope >= 0.0f && a->slope <= 1.0f)) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: slope must lie in [0, 1]");
     if (a->x_cstride < 0 || a->out_cstride < 0 || a->x_bstride < 0 || a->out_bstride < 0)
         return vk_fail(VK_E_ARG, "vk_mrf_stage: negative stride");
     MrfDev q;
     memset(&q, 0, sizeof(q));
     q.a = *a;
+    int halo = 0;
     for (int r = 0; r < a->n_blocks; ++r) {
         const int k = a->taps[r];
         if (k < 1 || !(k & 1)) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: taps must be odd");
@@ -473,6 +478,7 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
             reach += (k - 1) / 2 * (a->dilation[r][j] + 1);
         }
         if (reach > VK_MRF_HALO) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: a resblock reaches further than 64 samples");
+        if (reach > halo) halo = reach;
         q.groups[r] = (a->channels / 32) * k * 2;
     }
     auto span = [&](int64_t cstride) -> int64_t { return ((int64_t)(a->channels - 1) * cstride + a->length) * 4; };
@@ -485,8 +491,9 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
         if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_mrf_stage: out overlaps x");
     }
     q.x_bytes = (unsigned)xb; q.out_bytes = (unsigned)ob;
-    const int out_cols = vk_mrf_window(*G) - 2 * VK_MRF_HALO;
-    dim3 grid((unsigned)((a->length + out_cols - 1) / out_cols), 1, (unsigned)a->batch);
+    q.halo = halo;                                       // columns recomputed on either side: the longest reach
+    q.out_cols = vk_mrf_window(*G) - 2 * halo;
+    dim3 grid((unsigned)((a->length + q.out_cols - 1) / q.out_cols), 1, (unsigned)a->batch);
     int e = vk_launch_mrf_bf16(a->channels, q, grid, vk_mrf_lds_bytes(*G), (hipStream_t)stream);
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: this channel count is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));

@@ -3,7 +3,7 @@
 
 #define VK_MRF_CASE(G)                                                                           \
     if (channels == 32 * G.wm) {                                                                 \
-        auto k = mrf_stage_bf16_kernel<G.wm, G.wn, G.nt, G.two != 0>;                            \
+        auto k = mrf_stage_bf16_kernel<G.wm, G.wn, G.nt, G.two != 0, G.sum != 0>;                \
         static std::atomic<unsigned long long> lds_raised{0};   /* bit d: limit raised on device d */\
         if (hipError_t e = vk_allow_lds(k, lds, lds_raised); e != hipSuccess) return (int)e;     \
         hipLaunchKernelGGL(k, grid, dim3(64 * G.wm * G.wn), lds, s, q);                          \
@@ -14,5 +14,7 @@ int vk_launch_mrf_bf16(int channels, const MrfDev& q, dim3 grid, size_t lds, hip
 {
     VK_MRF_CASE(kMrf32)
     VK_MRF_CASE(kMrf64)
+    VK_MRF_CASE(kMrf128)
+    VK_MRF_CASE(kMrf256)
     return -1;
 }

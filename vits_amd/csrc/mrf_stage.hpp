@@ -9,9 +9,9 @@
 // matrix instruction; bias, residual chain and the sum over resblocks stay fp32).
 //
 // A workgroup owns every channel of a window of W = 32 * NT * WN time steps (WN waves along time,
-// NT adjacent 32-column tiles per wave), of which the inner W - 128 are outputs and 64 on each
-// side are halo (a resblock's receptive half-width: 12 / 36 / 60 samples for kernel sizes
-// 3 / 7 / 11 with dilations 1, 3, 5).  Nothing but the stage input and the stage output touches HBM:
+// NT adjacent 32-column tiles per wave), of which the inner W - 2 * halo are outputs; halo is the
+// longest receptive half-width among the launch's resblocks (12 / 36 / 60 samples for kernel
+// sizes 3 / 7 / 11 with dilations 1, 3, 5).  Nothing but the stage input and the stage output touches HBM:
 //   * the residual stream x_r lives in REGISTERS, in accumulator layout: a wave owns 32 channels
 //     of its NT tiles, so `x_r = conv2(...) + x_r` is a register add and the sum over the
 //     resblocks (kernel sizes) is accumulated in registers too;
@@ -36,18 +36,24 @@ constexpr int VK_MRF_HALO   = 64;
 constexpr int VK_MRF_GUARD  = 32;                           // addressable columns on either side of an image
 
 // geometry by channel count: waves along channels (32 each) x waves along time, tiles per wave
-struct MrfGeom { int wm, wn, nt, two; };
-static constexpr MrfGeom kMrf32 = {1, 4, 4, 0};             // 512-column window, 4 waves, one image (46 KB)
-static constexpr MrfGeom kMrf64 = {2, 4, 4, 0};             // 512-column window, 8 waves, one image (83 KB)
+// sum = 1: the launch sums several resblocks (a third register copy of the window);
+// sum = 0: one resblock per launch, out = resblock(x)
+struct MrfGeom { int wm, wn, nt, two, sum; };
+static constexpr MrfGeom kMrf32  = {1, 4, 4, 0, 1};         // 512-column window, 4 waves, one image (46 KB)
+static constexpr MrfGeom kMrf64  = {2, 4, 4, 0, 1};         // 512-column window, 8 waves, one image (83 KB)
+static constexpr MrfGeom kMrf128 = {4, 2, 4, 0, 0};         // 256-column window, 8 waves, one image (87 KB)
+static constexpr MrfGeom kMrf256 = {8, 1, 4, 0, 0};         // 128-column window, 8 waves, one image (101 KB)
 static inline const MrfGeom* vk_mrf_geom(int channels)
 {
-    return channels == 32 ? &kMrf32 : channels == 64 ? &kMrf64 : nullptr;
+    return channels == 32 ? &kMrf32 : channels == 64 ? &kMrf64 : channels == 128 ? &kMrf128 :
+           channels == 256 ? &kMrf256 : nullptr;
 }
 static inline int vk_mrf_window(const MrfGeom& g) { return 32 * g.nt * g.wn; }
 
 struct MrfDev {
     vk_mrf_args a;
     unsigned x_bytes, out_bytes;    // byte spans of one batch item's views
+    int halo, out_cols;             // recomputed columns on either side of a window; output columns per workgroup
     int groups[VK_MRF_MAX_BLOCKS];  // 64-lane x 16-byte groups per 32-row tile of a conv of block r: chunks * taps * 2
 };
 
@@ -58,12 +64,11 @@ static inline size_t vk_mrf_lds_bytes(const MrfGeom& g)
          + (size_t)VK_MRF_MAX_BLOCKS * VK_MRF_MAX_PAIRS * 2 * channels * sizeof(float);
 }
 
-template <int WM, int WN, int NT, bool TWO>
+template <int WM, int WN, int NT, bool TWO, bool SUM>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 mrf_stage_bf16_kernel(const MrfDev q)
 {
     constexpr int WIN = 32 * NT * WN;           // window columns
-    constexpr int OUT = WIN - 2 * VK_MRF_HALO;  // output columns
     constexpr int C   = 32 * WM;
     constexpr int NCH = C / 32;                 // K-chunks of 32 channels (two matrix instructions per tap each)
     constexpr int KS  = 2;
@@ -83,10 +88,10 @@ mrf_stage_bf16_kernel(const MrfDev q)
     const int half = lane >> 5;
     const int l31  = lane & 31;
     const int b    = blockIdx.z;
-    const int t0   = blockIdx.x * OUT;
+    const int t0   = blockIdx.x * q.out_cols;
     const int L    = p.length;
     const int col0 = wn * (32 * NT) + l31;      // this lane's window column in its first tile
-    const int tw   = t0 - VK_MRF_HALO + col0;   // ... and its time step
+    const int tw   = t0 - q.halo + col0;        // ... and its time step
 
     // every conv's bias, once, into LDS: entry ((r * n_pairs + j) * 2 + which) * C + channel
     for (int i = threadIdx.x; i < p.n_blocks * p.n_pairs * 2 * C; i += 64 * WM * WN) {
@@ -161,11 +166,13 @@ mrf_stage_bf16_kernel(const MrfDev q)
     };
 
     const __amdgpu_buffer_rsrc_t r_x = vk_rsrc(p.x + (int64_t)b * p.x_bstride, q.x_bytes);
-    f32x16 xr[NT], tot[NT];
+    f32x16 xr[NT], tot[SUM ? NT : 1];
+    if (SUM) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot[n][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) tot[n][r] = 0.0f;
+    }
 
     for (int blk = 0; blk < p.n_blocks; ++blk) {
         // the stage input, straight into accumulator layout (32 lanes = 128 contiguous bytes of a row;
@@ -209,10 +216,12 @@ mrf_stage_bf16_kernel(const MrfDev q)
                 __syncthreads();
             }
         }
+        if (SUM) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tot[n][r] += xr[n][r];
+                for (int r = 0; r < 16; ++r) tot[n][r] += xr[n][r];
+        }
         if (!TWO && blk + 1 < p.n_blocks) __syncthreads();     // the next resblock's input replaces h
     }
 
@@ -223,11 +232,12 @@ mrf_stage_bf16_kernel(const MrfDev q)
     for (int n = 0; n < NT; ++n) {
         const int c = col0 + 32 * n;
         const int t = tw + 32 * n;
-        if (c >= VK_MRF_HALO && c < VK_MRF_HALO + OUT && t < L) {
+        if (c >= q.halo && c < q.halo + q.out_cols && t < L) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + (r & 3) + 8 * (r >> 2);
-                vk_bst(tot[n][r] / nb, r_out, 4 * (t + 4 * half * (int)p.out_cstride), row * (int)p.out_cstride * 4);
+                const float v = SUM ? tot[n][r] / nb : xr[n][r];
+                vk_bst(v, r_out, 4 * (t + 4 * half * (int)p.out_cstride), row * (int)p.out_cstride * 4);
             }
         }
     }

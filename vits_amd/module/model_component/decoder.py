@@ -67,6 +67,20 @@ class ResBlockPlan:
                 self.pairs.append((PackedConv(c1.effective_weight(), c1.bias, device, dilation=d),
                                    PackedConv(c2.effective_weight(), c2.bias, device, dilation=1)))
         self.taps = k
+        # A resblock of short kernels as ONE launch (the three pairs chained in registers / LDS):
+        # its pair launches wait on memory, and a workgroup of the chained form recomputes only
+        # `reach` columns per side.  Longer kernels (reach 36 / 60) lose more to the recompute than
+        # they save.  Only where the stage kernel takes one resblock per launch (128 channels);
+        # narrower stages run whole through it.
+        self.chain = None
+        mi = native.mrf_info(rb.channels, prec) if prec == native.PREC_BF16 else None
+        reach = sum((k - 1) // 2 * (d + 1) for d in rb.dilation) if k % 2 == 1 else 1 << 30
+        if (self.fused and mi is not None and os.environ.get("VITS_AMD_MRF_FUSION", "1") != "0"
+                and reach <= self.chain_max_reach and len(rb.dilation) <= native.MRF_MAX_PAIRS
+                and all((k - 1) // 2 * d <= 32 for d in rb.dilation)):
+            self.chain = [(k, self.pairs)]
+
+    chain_max_reach = 16
 
     def _run_fused(self, x, tmp, run_buf, final_out, final_epi, acc_in, navg, before_final=None):
         # pairs ping-pong between the two scratch buffers: a pair's output may not land on its
@@ -93,6 +107,13 @@ class ResBlockPlan:
         residual, or residual + accumulation over resblocks); earlier pairs update ``run_buf``
         (and ``tmp``).  ``before_final`` is called just before the launch that touches
         ``final_out`` / ``acc_in`` (where a concurrent branch orders itself after its predecessor)."""
+        if self.chain is not None and final_epi == native.EPI_RESID:
+            if final_out.data_ptr() == x.data_ptr():
+                raise native.NativeError("resblock: the output buffer aliases the input")
+            if before_final is not None:
+                before_final()
+            native.mrf_stage(x, final_out, self.chain, slope=LRELU_SLOPE)
+            return final_out
         if self.fused:
             return self._run_fused(x, tmp, run_buf, final_out, final_epi,
                                    acc_in if final_epi != native.EPI_RESID else None, navg, before_final)
@@ -171,7 +192,7 @@ class DecoderPlan:
         if os.environ.get("VITS_AMD_MRF_FUSION", "1") == "0" or precision() != native.PREC_BF16:
             return None
         mi = native.mrf_info(ch, native.PREC_BF16)
-        if mi is None or nrb > native.MRF_MAX_BLOCKS or any(len(rb.dilation) != len(rbs[0].dilation) for rb in rbs) \
+        if mi is None or nrb > mi.max_blocks or any(len(rb.dilation) != len(rbs[0].dilation) for rb in rbs) \
                 or len(rbs[0].dilation) > native.MRF_MAX_PAIRS:
             return None
         for rb in rbs:
@@ -228,20 +249,16 @@ class Decoder(nn.Module):
     # The resblocks of a stage are independent until their last convolution adds into the stage
     # output, so each can run on a stream of its own; the last launches are chained by events in
     # the reference's summation order (decoder.py:119-125), which keeps the result bit-identical.
-    # Used (a) with few utterances in flight, where one convolution does not fill 256 CUs, and
-    # (b) with bf16 matrix inputs at any size: there the short-kernel launches wait on memory and
-    # the long-kernel ones on the matrix cores, and workgroups of both kinds sharing a CU is
-    # worth 4 % of the batch-16 step.  The fp32 modes stay serial at large sizes (+2 % only, and
-    # per-launch device times stay attributable to one kernel).
-    concurrent_branch_frames = 2048         # fp32: use branch streams when batch * frames is at most this
+    # Used with few utterances in flight, where one convolution does not fill 256 CUs.  At large
+    # sizes the streams are worth 0-2 % (measured at batch 16) and per-launch device times stop
+    # being attributable to one kernel, so large batches run the resblocks one after another.
+    concurrent_branch_frames = 2048         # use branch streams when batch * frames is at most this
 
     def _branches_concurrent(self, batch, frames):
-        from ...engine import precision
         mode = os.environ.get("VITS_AMD_BRANCH_STREAMS", "auto")
         if mode in ("0", "off"):
             return False
-        return (mode in ("1", "on") or batch * frames <= self.concurrent_branch_frames
-                or precision() == native.PREC_BF16)
+        return mode in ("1", "on") or batch * frames <= self.concurrent_branch_frames
 
     def _run_branches_concurrently(self, plan, stage, xu, xs, epis):
         nrb = self.num_resnet_blocks

@@ -33,7 +33,7 @@ _fp = C.c_void_p
 class TileInfo(C.Structure):
     _fields_ = [("ck", C.c_int32), ("rows_per_block", C.c_int32),
                 ("time_tile", C.c_int32), ("a_rep", C.c_int32), ("ck_bf16", C.c_int32),
-                ("ck_split", C.c_int32)]
+                ("ck_split", C.c_int32), ("max_blocks", C.c_int32)]
 
 
 class ConvArgs(C.Structure):
