@@ -87,13 +87,8 @@ def cpu_model() -> str:
 def csrc_hash() -> str:
     """Fingerprint of the kernel sources; the stored HBM-traffic figures carry the one they were
     measured with."""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "vits_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    from vits_amd.build import csrc_hash as h
+    return h()
 
 
 def cpu_baseline(sd, frames: int, budget_s: float):
@@ -305,42 +300,50 @@ def main():
     if rank == 0:
         fam = fam_all                                   # per-family table of the surveyed (untimed) step
         name, dom = dominant, timer.summary()[dominant] # the dominant family over the timed region
-        traffic, traffic_stale = None, None  # HBM bytes per launch from the committed counter passes of this workload
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if args.workload == "batch" and (B, T) == (16, 862) and args.precision == "fp32" and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = tj["by_family"].get(name, {}).get("hbm_bytes_per_launch")
-            traffic_stale = tj.get("csrc_hash") != csrc_hash()
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        total_ms = sum(d["ms"] for d in fam.values())
-        total_flops = sum(d["flops"] for d in fam.values())
-        common = {"kernel": name, "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
-                  "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
-                  "mb_per_launch": dom["bytes"] / dom["launches"] / 1e6,
-                  "share_of_device_time": fam[name]["ms"] / total_ms,
-                  "all_kernels_tflops": total_flops / (total_ms * 1e-3) / 1e12}
-        if args.precision == "fp32":
-            roof = {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_stale": traffic_stale,
-                    "traffic_note": "HBM bytes per launch, rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes "
-                                    "stored in profiles/hbm_traffic.json" if traffic else None}
-        elif args.precision == "fp32-split":
-            # six bf16 slice products per fp32 product: the matrix-core ceiling in algorithmic FLOPs
-            peak = BF16_MATRIX_PEAK_TFLOPS / 6.0
-            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": None, "peak_note": "dense bf16 MFMA peak / 6 slice products per fp32 product"}
-        else:
-            # bf16 matrix inputs: whichever of the two roofs the family's launches sit under
-            t_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
-            t_mfma = dom["flops"] / (BF16_MATRIX_PEAK_TFLOPS * 1e12)
-            if t_hbm >= t_mfma:
-                gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-                roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "traffic": None}
+        def make_roofline(prec, name, dom, fam):
+            """The roofline object of kernel family ``name``: ``dom`` holds its launches' summed FLOPs,
+            bytes and device time, ``fam`` the table of every family of one step."""
+            traffic, traffic_stale = None, None     # HBM bytes per launch from the committed counter passes
+            tname = "hbm_traffic.json" if prec == "fp32" else f"hbm_traffic_{prec}.json"
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if args.workload == "batch" and (B, T) == (16, 862) and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                traffic = tj["by_family"].get(name, {}).get("hbm_bytes_per_launch")
+                traffic_stale = tj.get("csrc_hash") != csrc_hash()
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            total_ms = sum(d["ms"] for d in fam.values())
+            total_flops = sum(d["flops"] for d in fam.values())
+            common = {"traffic": traffic, "traffic_stale": traffic_stale,
+                      "traffic_note": ("HBM bytes per launch, rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes "
+                                       f"stored in profiles/{tname}") if traffic else None,
+                      "kernel": name, "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                      "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+                      "mb_per_launch": dom["bytes"] / dom["launches"] / 1e6,
+                      "share_of_device_time": fam[name]["ms"] / total_ms,
+                      "all_kernels_tflops": total_flops / (total_ms * 1e-3) / 1e12}
+            if prec == "fp32":
+                r = {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MATRIX_PEAK_TFLOPS}
+            elif prec == "fp32-split":
+                # six bf16 slice products per fp32 product: the matrix-core ceiling in algorithmic FLOPs
+                peak = BF16_MATRIX_PEAK_TFLOPS / 6.0
+                r = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "peak_note": "dense bf16 MFMA peak / 6 slice products per fp32 product"}
             else:
-                roof = {"bound": "mfma", "achieved": achieved, "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / BF16_MATRIX_PEAK_TFLOPS, "traffic": None}
-        roof.update(common)
+                # bf16 matrix inputs: whichever of the two roofs the family's launches sit under
+                t_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
+                t_mfma = dom["flops"] / (BF16_MATRIX_PEAK_TFLOPS * 1e12)
+                if t_hbm >= t_mfma:
+                    gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+                    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS}
+                else:
+                    r = {"bound": "mfma", "achieved": achieved, "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / BF16_MATRIX_PEAK_TFLOPS}
+            r.update(common)
+            return r
+
+        roof = make_roofline(args.precision, name, dom, fam)
         line = {
             "metric": "audio seconds generated/sec (RTF^-1), 10 s utterances",
             "value": job["value"], "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -384,10 +387,18 @@ def main():
                     w2 = step()
                 torch.cuda.synchronize(dev)
                 dt = (time.perf_counter() - t1) / 3
+                sv = native.LaunchTimer()           # one more step with every launch bracketed
+                with sv:
+                    step()
+                torch.cuda.synchronize(dev)
+                fam2 = sv.summary()
+                dom2 = max(fam2.items(), key=lambda kv: kv[1]["ms"])[0]
                 others[prec] = {"ms_per_step": 1e3 * dt, "value": B * T * HOP / SAMPLE_RATE / dt,
                                 "dtype": DTYPE_NAMES[prec],
                                 "parity_max_abs": max(float((w2[i:i + 1].cpu() - ref[i]).abs().max()) for i in items),
-                                "tol": BF16_TOL if prec == "bf16" else PARITY_TOL}
+                                "tol": BF16_TOL if prec == "bf16" else PARITY_TOL,
+                                "roofline": make_roofline(prec, dom2, fam2[dom2], fam2),
+                                "roofline_note": "dominant family of one step with every launch bracketed by events"}
                 if others[prec]["parity_max_abs"] > others[prec]["tol"]:
                     failures.append(f"{prec}: differs from the CPU oracle by {others[prec]['parity_max_abs']:.3e}")
             engine.set_precision(args.precision)

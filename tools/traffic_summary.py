@@ -49,8 +49,16 @@ for k, v in out.items():
     args = [a.strip() for a in k[k.index("<") + 1:k.index(">")].split(",")]
     if k.startswith("void conv_mfma_kernel"):
         fam = f"conv_mfma[{TILES.get(tuple(args[:4]), '?')},{EPIS[int(args[5])]},act={int(args[6] == 'true')}]"
+    elif k.startswith("void conv_bf16_kernel"):
+        fam = f"conv_bf16[{TILES.get(tuple(args[:4]), '?')},{EPIS[int(args[5])]},act={int(args[6] == 'true')}]"
+    elif k.startswith("void conv_split_kernel"):
+        fam = f"conv_split[{TILES.get(tuple(args[:4]), '?')},{EPIS[int(args[5])]},act={int(args[6] == 'true')}]"
     elif k.startswith("void resblock_pair_kernel"):
         fam = f"resblock_pair[c{32 * int(args[1])},{EPIS[int(args[4])]}]"
+    elif k.startswith("void resblock_pair_bf16_kernel"):
+        fam = f"resblock_pair_bf16[c{32 * int(args[0]) * int(args[2])},{EPIS[int(args[4])]}]"
+    elif k.startswith("void mrf_stage_bf16_kernel"):
+        fam = f"mrf_stage_bf16[c{32 * int(args[0])}]"
     else:
         continue
     f = fams.setdefault(fam, dict(dispatches=0, fetch=0.0, write=0.0))
@@ -62,6 +70,9 @@ by_family = {fam: dict(dispatches=f["dispatches"],
                        write_bytes_per_launch=f["write"] / f["dispatches"],
                        hbm_bytes_per_launch=(f["fetch"] + f["write"]) / f["dispatches"]) for fam, f in fams.items()}
 if len(sys.argv) > 3:
-    json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps 1 --warmup 1`; "
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vits_amd.build import csrc_hash
+    json.dump(dict(csrc_hash=csrc_hash(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps 1 --warmup 1`; "
                         "FETCH_SIZE doubled (gfx950 tallies 128-byte read requests as 64 bytes); bytes per launch",
                    by_family=by_family, by_symbol=out), open(sys.argv[3], "w"), indent=1)

@@ -186,10 +186,13 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     }
     // Placing the row blocks of a time tile on one XCD cuts the fetched bytes of the multi-row-block
     // launches by 2-4x (one HBM read of the x tile per XCD instead of one per row block).  It pays where
-    // the kernel is HBM-bound (bf16 inputs); the fp32 kernels are MFMA-bound and run 0.4 % slower with it.
+    // the kernel is HBM-bound (bf16 inputs, +2 %); the fp32 kernels are MFMA-bound and their time does
+    // not depend on it (256 channels: -0.6 % at 7 taps, 0 at 11, +6 % for the short 3-tap residual
+    // launches, 0.1 % of a decoder step in all), so it is on there too and the wasted re-reads go.
+    // The sliced-fp32 kernel walks its tiles in an order of its own.
     // (Diagnostic build: VK_XCD_MAP=0 / 1 forces it off / on for every precision.)
     static const int xcd_env = diag_env("VK_XCD_MAP", -1);
-    d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : a->precision == VK_PREC_BF16);
+    d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : !split);
     if (d->xcd_map)
         *grid = dim3((unsigned)(8 * ((d->n_tiles + 7) / 8) * d->n_rowblk), 1, (unsigned)a->batch);
     else

@@ -95,11 +95,11 @@ struct Bf16Stager {
 constexpr int VK_PF = VK_BF16_PF;
 
 // a[i] = fragments of tap i of the stream `aptr` points into (i < VK_PF)
-template <int KS, int A_REP>
-__device__ __forceinline__ void bf16_wload(bf16x8 (&a)[VK_PF][KS][A_REP], const bf16x8* (&aptr)[A_REP])
+template <int KS, int A_REP, int PF = VK_PF>
+__device__ __forceinline__ void bf16_wload(bf16x8 (&a)[PF][KS][A_REP], const bf16x8* (&aptr)[A_REP])
 {
 #pragma unroll
-    for (int i = 0; i < VK_PF; ++i)
+    for (int i = 0; i < PF; ++i)
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
@@ -107,12 +107,12 @@ __device__ __forceinline__ void bf16_wload(bf16x8 (&a)[VK_PF][KS][A_REP], const 
 }
 
 // The k-loop over one resident chunk (KS matrix instructions per tap): weights fetched VK_PF taps
-// ahead, B fragments of the next k-step read before the current k-step's MFMAs are issued.
+// ahead (PF), B fragments of the next k-step read before the current k-step's MFMAs are issued.
 // `base` is this lane's fragment address for tap 0 / k-step 0 / column tile 0.  The weight stream
 // runs on linearly past the chunk (next chunk, next row tile or the zero groups that end a packed
 // tensor), so a[] arrives holding the current tap and leaves holding the next chunk's first.
-template <int A_REP, int B_REP, int KS, int PITCH>
-__device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&a)[VK_PF][KS][A_REP],
+template <int A_REP, int B_REP, int KS, int PITCH, int PF = VK_PF>
+__device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&a)[PF][KS][A_REP],
                                           const bf16x8* (&aptr)[A_REP], const char* base, int taps, int tap_step)
 {
     const char* bt = base;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
-            for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = aptr[m][64 * (KS * VK_PF + k)];
+            for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = aptr[m][64 * (KS * PF + k)];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             bf16x8 bn[B_REP];
@@ -150,8 +150,8 @@ __device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&
 #pragma unroll
             for (int m = 0; m < A_REP; ++m) {
 #pragma unroll
-                for (int i = 0; i + 1 < VK_PF; ++i) a[i][k][m] = a[i + 1][k][m];
-                a[VK_PF - 1][k][m] = a_nxt[k][m];
+                for (int i = 0; i + 1 < PF; ++i) a[i][k][m] = a[i + 1][k][m];
+                a[PF - 1][k][m] = a_nxt[k][m];
             }
     }
 }

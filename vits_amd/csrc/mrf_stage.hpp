@@ -74,6 +74,9 @@ mrf_stage_bf16_kernel(const MrfDev q)
     constexpr int KS  = 2;
     constexpr int PITCH = C * 2 + 16;           // bytes per column (odd multiple of 16: conflict-free 16-byte reads)
     constexpr int IMG = (WIN + 2 * VK_MRF_GUARD) * PITCH;
+    // three register copies of a four-tile window leave no room for a second tap of weight
+    // fragments in flight (the compiler would spill, and spills are HBM traffic)
+    constexpr int PF  = (SUM && NT >= 4) ? 1 : VK_PF;
 
     extern __shared__ __attribute__((aligned(16))) char lds8[];
     char* img_a = lds8;                         // bf16(lrelu(x_r)): input of the dilated convs
@@ -109,10 +112,10 @@ mrf_stage_bf16_kernel(const MrfDev q)
     auto wfrag = [&](const void* wp, int groups) {
         return reinterpret_cast<const bf16x8*>(wp) + ((int64_t)wm * groups) * 64 + lane;
     };
-    bf16x8 a_pre[VK_PF][KS][1];
+    bf16x8 a_pre[PF][KS][1];
     {
         const bf16x8* first[1] = {wfrag(p.w1[0][0], q.groups[0])};
-        bf16_wload<KS, 1>(a_pre, first);
+        bf16_wload<KS, 1, PF>(a_pre, first);
     }
 
     // accumulator-layout register r of a lane is channel 32*wm + (r & 3) + 8*(r >> 2) + 4*half;
@@ -139,7 +142,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
 
     // one convolution of this wave's three tiles: bias, then every chunk's taps out of an image
     f32x16 acc[1][NT];
-    bf16x8 a[VK_PF][KS][1];
+    bf16x8 a[PF][KS][1];
     const bf16x8* aptr[1];
     auto conv = [&](const char* img, int conv_index, const void* wp, int groups, int taps, int dilation,
                     const void* w_next, int groups_next) {
@@ -152,17 +155,17 @@ mrf_stage_bf16_kernel(const MrfDev q)
         }
         aptr[0] = wfrag(wp, groups);
 #pragma unroll
-        for (int i = 0; i < VK_PF; ++i)
+        for (int i = 0; i < PF; ++i)
 #pragma unroll
             for (int k = 0; k < KS; ++k) a[i][k][0] = a_pre[i][k][0];
         if (w_next != nullptr) {                                    // wave-uniform
             const bf16x8* nx[1] = {wfrag(w_next, groups_next)};
-            bf16_wload<KS, 1>(a_pre, nx);
+            bf16_wload<KS, 1, PF>(a_pre, nx);
         }
         const int pad = ((taps - 1) >> 1) * dilation;
         const char* base = img + (VK_MRF_GUARD + col0 - pad) * PITCH + half * 16;
         for (int chunk = 0; chunk < NCH; ++chunk)
-            bf16_taps<1, NT, KS, PITCH>(acc, a, aptr, base + chunk * 64, taps, dilation * PITCH);
+            bf16_taps<1, NT, KS, PITCH, PF>(acc, a, aptr, base + chunk * 64, taps, dilation * PITCH);
     };
 
     const __amdgpu_buffer_rsrc_t r_x = vk_rsrc(p.x + (int64_t)b * p.x_bstride, q.x_bytes);
