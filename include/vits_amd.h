@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 5
+#define VK_ABI_VERSION 6
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -120,7 +120,17 @@ typedef struct {
     int32_t precision;    /* VK_PREC_* (selects the packed weight format too) */
     int32_t narrow;       /* 1: half the family's time tile (twice the workgroups, same packed weights);
                              for launches too small to fill the GPU.  VK_PREC_F32 only, ignored otherwise */
+    /* Scratch for launches too small to fill the GPU (VK_PREC_F32 only): with it, such a launch
+     * splits the channel loop over up to 8 workgroups per output tile; each writes its partial
+     * accumulators here and the last one to arrive adds them in a fixed order and runs the
+     * epilogue.  NULL: no split.  vk_conv1d_workspace_bytes says how much a launch uses.  The
+     * first VK_WS_COUNTER_BYTES hold arrival counters: zero before the first use, and every
+     * launch leaves them zero again.  Launches that may overlap in time (other streams) need
+     * workspaces of their own. */
+    void*   workspace;    int64_t workspace_bytes;
 } vk_conv_args;
+
+#define VK_WS_COUNTER_BYTES 65536
 
 int         vk_abi_version(void);
 const char* vk_last_error(void);
@@ -139,6 +149,12 @@ int64_t     vk_conv1d_lds_bytes(const vk_conv_args* a);
  * decoder.py:49-58,112,115-117 ; wn.py:70-85 ; flow.py:54,58-67 ;
  * posterior_encoder.py:52,56-59.                                                     */
 int vk_conv1d(const vk_conv_args* a, void* stream);
+
+/* Bytes of `workspace` this launch would use (counters included), 0 if it does not split, or a
+ * negative VK_E_* code.  A launch splits when it has fewer than 128 workgroups and at least 4
+ * channel chunks; never more than VK_WS_MAX_BYTES. */
+#define VK_WS_MAX_BYTES (VK_WS_COUNTER_BYTES + (16 << 20))
+int64_t vk_conv1d_workspace_bytes(const vk_conv_args* a);
 
 /* ---- fused residual pair of a HiFi-GAN resblock ------------------------------------
  *   h   = conv1(lrelu(x, slope))            taps k, dilation d, padding (k-1)*d/2

@@ -1,6 +1,8 @@
 """Kernel-level GPU tests through the C ABI: the fused convolution against plain PyTorch fp32
 ops on the CPU, over odd shapes (lengths below one tile, not multiples of 4, channel counts
 that are not multiples of the K-chunk), every tile family and every epilogue."""
+import ctypes as C
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -384,7 +386,9 @@ def test_split3_is_exact():
     (513, 192, 1, 1, 1, 50, False),
     (40, 72, 5, 2, 2, 130, True),
 ])
-def test_split_conv_matches_fp32(cin, cout, k, dil, B, L, act):
+def test_split_conv_matches_fp32(cin, cout, k, dil, B, L, act, monkeypatch):
+    # the yardstick below is the fp32 kernel's one long accumulation chain: keep its channel loop whole
+    monkeypatch.setattr(native, "SPLIT_SMALL_LAUNCHES", False)
     x = _rand(B, cin, L, seed=111)
     w = _rand(cout, cin, k, seed=112) / (cin * k) ** 0.5
     bias = _rand(B, cout, seed=113)
@@ -566,3 +570,71 @@ def test_fused_mrf_stage_rejects_bad_arguments():
     x8 = torch.zeros(1, 128, 64, device=DEV)
     with pytest.raises(native.NativeError):          # two resblocks in one launch at 128 channels
         native.mrf_stage(x8, torch.empty_like(x8), [(3, [(w8, b8, w8, b8, 1)])] * 2, slope=0.1)
+
+
+# ---- split channel loop of launches too small to fill the GPU (fp32 kernel, scratch workspace) ----
+@pytest.mark.parametrize("cin,cout,k,dil,B,L", [
+    (256, 256, 11, 1, 1, 2064),      # decoder stage 1 of a 3 s utterance: 66 workgroups, 4 splits
+    (256, 256, 3, 5, 1, 70),
+    (192, 512, 7, 1, 1, 258),
+    (512, 256, 7, 1, 2, 33),
+    (64, 64, 7, 3, 1, 300),          # exactly 4 chunks: 2 splits
+])
+def test_split_channel_loop_matches_the_single_workgroup_form(cin, cout, k, dil, B, L, monkeypatch):
+    x = _rand(B, cin, L, seed=301).to(DEV)
+    w = _rand(cout, cin, k, seed=302) / (cin * k) ** 0.5
+    bias = _rand(cout, seed=303).to(DEV)
+    res = _rand(B, cout, L, seed=304).to(DEV)
+    pad = (k - 1) * dil // 2
+    tile = choose_tile(cout)
+    wp = _pack(w, tile)
+
+    def run(split):
+        monkeypatch.setattr(native, "SPLIT_SMALL_LAUNCHES", split)
+        out = torch.full((B, cout, L), float("nan"), device=DEV)
+        native.conv1d(x, wp, out, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                      epilogue=native.EPI_RESID, bias=bias, res=res, act_in=True, in_slope=0.1)
+        return out
+
+    a = native.ConvArgs()
+    one = run(False)
+    two = run(True)
+    three = run(True)                                  # the counters were left at zero
+    ref = F.conv1d(F.leaky_relu(x.cpu(), 0.1), w, bias.cpu(), padding=pad, dilation=dil) + res.cpu()
+    _close(two, ref, "split channel loop")
+    assert torch.equal(two, three)                     # fixed summation order: run-to-run identical
+    assert (one - two).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert not torch.equal(one, two) or cin * k < 64   # the split really ran (another summation order)
+    ws = native.workspace(DEV)
+    assert int(ws[:native.WS_COUNTER_BYTES // 4].view(torch.int32).abs().max()) == 0
+
+
+def test_split_channel_loop_workspace_contract():
+    B, cin, cout, k, L = 1, 256, 256, 7, 2064
+    x = _rand(B, cin, L, seed=311).to(DEV)
+    wp = _pack(_rand(cout, cin, k, seed=312) / (cin * k) ** 0.5, choose_tile(cout))
+    out = torch.empty(B, cout, L, device=DEV)
+    a = native.ConvArgs()
+    a.x, a.x_bstride, a.x_cstride = native._view(x)
+    a.out, a.out_bstride, a.out_cstride = native._view(out)
+    a.w = wp.data_ptr()
+    a.batch, a.c_in, a.c_out, a.length = B, cin, cout, L
+    a.taps, a.dilation, a.pad, a.tile, a.epilogue, a.narrow = k, 1, 3, choose_tile(cout), native.EPI_STORE, 1
+    L_ = native.lib()
+    need = L_.vk_conv1d_workspace_bytes(C.byref(a))
+    # 33 tiles x 2 row blocks = 66 workgroups -> 3 splits of a 128 x 64 tile
+    assert need == native.WS_COUNTER_BYTES + 66 * 3 * 128 * 64 * 4
+    sp = native.stream_ptr(x.device)
+    assert L_.vk_conv1d(C.byref(a), sp) == 0           # no workspace: runs unsplit
+    small = torch.zeros(need // 4 - 1, device=DEV)
+    a.workspace, a.workspace_bytes = small.data_ptr(), small.numel() * 4
+    assert L_.vk_conv1d(C.byref(a), sp) == -2
+    assert b"scratch" in L_.vk_last_error()
+    a.tile, a.c_out = native.TILE_M128, 256
+    big = _rand(16, cin, 6896, seed=313).to(DEV)       # a launch that fills the GPU does not split
+    a.x, a.x_bstride, a.x_cstride = native._view(big)
+    o2 = torch.empty(16, cout, 6896, device=DEV)
+    a.out, a.out_bstride, a.out_cstride = native._view(o2)
+    a.batch, a.length, a.narrow = 16, 6896, 0
+    assert L_.vk_conv1d_workspace_bytes(C.byref(a)) == 0
+    torch.cuda.synchronize()

@@ -69,7 +69,10 @@ static int64_t gemm_rows(const vk_conv_args* a)
     return a->c_out;
 }
 
-static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, int* vec)
+// `ws` / `ws_bytes`: the scratch a split channel loop may use (null: the launch does not split);
+// `query`: only work out how much it would use (*ws_need), whatever scratch there is.
+static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, int* vec,
+                  void* ws, int64_t ws_bytes, int64_t* ws_need, bool query, const char* who = "vk_conv1d")
 {
     if (!a) return vk_fail(VK_E_ARG, "vk_conv1d: null argument block");
     if (!a->x || !a->w || !a->out) return vk_fail(VK_E_ARG, "vk_conv1d: null x / w / out pointer");
@@ -193,7 +196,35 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     // (Diagnostic build: VK_XCD_MAP=0 / 1 forces it off / on for every precision.)
     static const int xcd_env = diag_env("VK_XCD_MAP", -1);
     d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : !split);
-    if (d->xcd_map)
+    // A launch far too small for 256 CUs splits its channel loop over several workgroups per output
+    // tile (fp32 kernel only): as many as bring it to about one workgroup per CU, at least two
+    // chunks each, at most 8.  The partial accumulators and arrival counters live in scratch memory.
+    d->ksplit = 1;
+    d->ws = nullptr;
+    *ws_need = 0;
+    const int64_t wgs = (int64_t)d->n_tiles * d->n_rowblk * a->batch;
+    if (!bf16 && wgs < 128 && d->nchunk >= 4 && (query || ws != nullptr)) {
+        int k = (int)(256 / wgs);
+        if (k > d->nchunk / 2) k = d->nchunk / 2;
+        if (k > 8) k = 8;
+        if (k > 1) {
+            *ws_need = VK_WS_COUNTER_BYTES + wgs * k * (int64_t)rows_blk * TN * 4;
+            if (!query) {
+                if (*ws_need > ws_bytes) {
+                    snprintf(g_err, sizeof(g_err), "%s: the split channel loop of this launch needs %lld bytes of "
+                             "scratch, %lld are there", who, (long long)*ws_need, (long long)ws_bytes);
+                    return VK_E_UNSUPPORTED;
+                }
+                if ((uintptr_t)ws % 16) return vk_fail(VK_E_ARG, "vk_conv1d: workspace must be 16-byte aligned");
+                d->ksplit = k;
+                d->ws = static_cast<float*>(ws);
+            }
+        }
+    }
+    if (d->ksplit > 1) {
+        d->xcd_map = 0;
+        *grid = dim3((unsigned)d->n_tiles, (unsigned)(d->n_rowblk * d->ksplit), (unsigned)a->batch);
+    } else if (d->xcd_map)
         *grid = dim3((unsigned)(8 * ((d->n_tiles + 7) / 8) * d->n_rowblk), 1, (unsigned)a->batch);
     else
         *grid = dim3((unsigned)d->n_tiles, (unsigned)d->n_rowblk, (unsigned)a->batch);
@@ -209,16 +240,30 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
 
 extern "C" int64_t vk_conv1d_lds_bytes(const vk_conv_args* a)
 {
-    ConvDev d; dim3 grid; size_t lds = 0; int vec = 0;
-    int rc = derive(a, &d, &grid, &lds, &vec);
+    ConvDev d; dim3 grid; size_t lds = 0; int vec = 0; int64_t need = 0;
+    int rc = derive(a, &d, &grid, &lds, &vec, nullptr, 0, &need, true);
     return rc == VK_OK ? (int64_t)lds : (int64_t)rc;
 }
 
+extern "C" int64_t vk_conv1d_workspace_bytes(const vk_conv_args* a)
+{
+    ConvDev d; dim3 grid; size_t lds = 0; int vec = 0; int64_t need = 0;
+    int rc = derive(a, &d, &grid, &lds, &vec, nullptr, 0, &need, true);
+    return rc == VK_OK ? need : (int64_t)rc;
+}
+
+static int conv1d_launch(const vk_conv_args* a, const ConvDev& d, dim3 grid, size_t lds, int vec, void* stream);
+
 extern "C" int vk_conv1d(const vk_conv_args* a, void* stream)
 {
-    ConvDev d; dim3 grid; size_t lds = 0; int vec = 0;
-    int rc = derive(a, &d, &grid, &lds, &vec);
+    ConvDev d; dim3 grid; size_t lds = 0; int vec = 0; int64_t need = 0;
+    int rc = derive(a, &d, &grid, &lds, &vec, a ? a->workspace : nullptr, a ? a->workspace_bytes : 0, &need, false);
     if (rc != VK_OK) return rc;
+    return conv1d_launch(a, d, grid, lds, vec, stream);
+}
+
+static int conv1d_launch(const vk_conv_args* a, const ConvDev& d, dim3 grid, size_t lds, int vec, void* stream)
+{
     hipStream_t s = (hipStream_t)stream;
     const int act = a->act_in ? 1 : 0;
     int e = -1;

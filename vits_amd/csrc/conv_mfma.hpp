@@ -60,6 +60,12 @@ struct ConvDev {
                         // from HBM once per XCD instead of once per row block
     int dbg;            // diagnostic build only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop,
                         // 4 = stage only the first chunk, 8 = barrier only on the first chunk
+    // Split of the channel loop (fp32 kernel only; 1 elsewhere).  With ksplit > 1, blockIdx.y
+    // enumerates (split, row block); workgroup `split` runs chunks [split * nchunk / ksplit,
+    // (split + 1) * nchunk / ksplit) and leaves its accumulators in `ws`; the last workgroup of an
+    // output tile to arrive adds the partials in split order and runs the epilogue.
+    int ksplit;
+    float* ws;          // VK_WS_COUNTER_BYTES of arrival counters (one per output tile), then the partials
 };
 
 // tanh(a) * sigmoid(b) on the hardware exp2 / reciprocal units (each about 1 ulp): ten vector
@@ -561,14 +567,19 @@ conv_mfma_kernel(const ConvDev d)
     const int half = lane >> 5;
     const int l31  = lane & 31;
     const int b    = blockIdx.z;
-    int tile = blockIdx.x, rowblk = blockIdx.y;
+    int tile = blockIdx.x, rowblk = blockIdx.y, split = 0;
     if (d.xcd_map) {
         // hardware deals consecutive workgroup ids round-robin over the 8 XCDs
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         rowblk = slot % d.n_rowblk;
         tile = (slot / d.n_rowblk) * 8 + xcd;
         if (tile >= d.n_tiles) return;                 // padding of the last tile group (whole workgroup leaves)
+    } else if (d.ksplit > 1) {
+        split = blockIdx.y / d.n_rowblk;
+        rowblk = blockIdx.y - split * d.n_rowblk;
     }
+    const int c_begin = split * d.nchunk / d.ksplit;       // this workgroup's share of the channel chunks
+    const int c_end   = (split + 1) * d.nchunk / d.ksplit;
     const int t0   = tile * TN;
     const int mt0  = (rowblk * WM + wm) * A_REP;       // first packed 32-row tile of this wave
     const int L    = p.length;
@@ -586,13 +597,14 @@ conv_mfma_kernel(const ConvDev d)
     stg.init(d, xb, t0, lane);
     auto issue_loads = [&](int chunk) { stg.issue(d, chunk, w); };
     auto store_chunk = [&](int chunk, float* buf) { stg.store(d, chunk, buf, w, lane); };
-    issue_loads(0);          // first: the longest latency of the prologue; weights and bias follow it
+    issue_loads(c_begin);    // first: the longest latency of the prologue; weights and bias follow it
 
     // ---- weight stream: one float4 per lane per 4 k-steps per row tile ----
     const float4* aptr[A_REP];
 #pragma unroll
     for (int m = 0; m < A_REP; ++m)
-        aptr[m] = reinterpret_cast<const float4*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
+        aptr[m] = reinterpret_cast<const float4*>(p.w)
+                + ((int64_t)(mt0 + m) * d.groups_per_mt + (int64_t)c_begin * p.taps * GPC) * 64 + lane;
 
     // Weight fragments of a tap live in GPC register groups; in the tap loop each group is
     // reloaded for the next tap as soon as its four k-steps have been issued, so the other
@@ -607,7 +619,8 @@ conv_mfma_kernel(const ConvDev d)
     {
         // accumulators start at the bias of their row: register r of a lane is row
         // (r & 3) + 8 * (r >> 2) + 4 * half of its 32-row tile
-        const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
+        // (of a split channel loop only the first share carries the bias)
+        const float* biasb = (p.bias && split == 0) ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
         const int rows_total_b = PAIR ? 2 * p.hidden : p.c_out;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) {
@@ -642,17 +655,17 @@ conv_mfma_kernel(const ConvDev d)
     const int bcol = half * STRIDE + wn * TNW + l31 + shift + d.col0;
     
     unsigned long long boundary_ticks = 0;      // diagnostic: time spent handing over chunks 1..n-1
-    for (int chunk = 0; chunk < d.nchunk; ++chunk) {
-        float* buf = lds + (chunk & 1) * (CK * STRIDE);
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        float* buf = lds + ((chunk - c_begin) & 1) * (CK * STRIDE);
         unsigned long long tb0 = 0;
         const int dbg = kDiag ? d.dbg : 0;
         const bool stamping = kDiag && d.stamps != nullptr;
         if (stamping) tb0 = __builtin_amdgcn_s_memrealtime();
-        if (!(dbg & 4) || chunk == 0) store_chunk(chunk, buf);
-        if (!(dbg & 8) || chunk == 0) __syncthreads();
-        if (chunk == 0) vk_stamp(d, 1);
+        if (!(dbg & 4) || chunk == c_begin) store_chunk(chunk, buf);
+        if (!(dbg & 8) || chunk == c_begin) __syncthreads();
+        if (chunk == c_begin) vk_stamp(d, 1);
         else if (stamping) boundary_ticks += __builtin_amdgcn_s_memrealtime() - tb0;
-        if (chunk + 1 < d.nchunk && !(dbg & 4)) issue_loads(chunk + 1);
+        if (chunk + 1 < c_end && !(dbg & 4)) issue_loads(chunk + 1);
         if (dbg & 2) continue;
 
         // k-steps walk channel pairs within a tap, then taps; the B fragments of the next
@@ -707,5 +720,47 @@ conv_mfma_kernel(const ConvDev d)
     if (kDiag && d.stamps != nullptr && threadIdx.x == 0)
         d.stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 4] = boundary_ticks;
     if (kDiag && (d.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+
+    if (d.ksplit > 1) {
+        // Split channel loop: partial accumulators go to the workspace in register order (a wave's
+        // register is 256 contiguous bytes); the workgroup that finds the tile's counter at
+        // ksplit - 1 is the last, adds the partials in split order (its own included, so the sum
+        // does not depend on who arrives last), clears the counter for the next launch and goes on.
+        constexpr int PER_WAVE = A_REP * B_REP * 16 * 64;
+        const int tile_id = (b * d.n_tiles + tile) * d.n_rowblk + rowblk;
+        unsigned* counter = reinterpret_cast<unsigned*>(d.ws) + tile_id;
+        float* part = d.ws + VK_WS_COUNTER_BYTES / 4 + ((size_t)tile_id * d.ksplit * NW + w) * PER_WAVE + lane;
+        float* mine = part + (size_t)split * NW * PER_WAVE;
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+            for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((m * B_REP + n) * 16 + r) * 64] = acc[m][n][r];
+        __threadfence();                               // partials visible device-wide before the count
+        __syncthreads();                               // (also: every wave is done with the staged tiles)
+        unsigned* arrived = reinterpret_cast<unsigned*>(lds);
+        if (threadIdx.x == 0) *arrived = atomicAdd(counter, 1u);
+        __syncthreads();
+        if (*arrived != (unsigned)(d.ksplit - 1)) return;
+        __threadfence();                               // the other workgroups' partials, not stale lines
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+            for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+        for (int sp = 0; sp < d.ksplit; ++sp) {
+            const float* src = part + (size_t)sp * NW * PER_WAVE;
+#pragma unroll
+            for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+                for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[m][n][r] += src[((m * B_REP + n) * 16 + r) * 64];
+        }
+        if (threadIdx.x == 0) *counter = 0u;
+    }
     conv_epilogue<A_REP, B_REP, EPI>(d, acc, b, t0, mt0, wn, half, l31);
 }

@@ -30,6 +30,7 @@ class WNPlan:
     """Packed weights of one WN stack on one device."""
 
     fused_max_columns = 16384
+    fused_min_columns = 448      # below: two launches per layer, each with its channel loop split over workgroups
 
     def __init__(self, wn: "WN", device):
         H, n = wn.hidden_channels, wn.n_resblocks
@@ -76,8 +77,11 @@ class WNPlan:
         cstride = cond.stride(0)
         # Measured on the MI355X: the one-launch layer wins for small batches (fewer dependent
         # launches: 6.85 -> 6.57 ms for one 10 s utterance), ties at 16 x 862 frames, and loses to
-        # the two-launch form beyond that (its 6-wave workgroups fill the SIMDs less evenly).
-        if self.fused and B * T <= self.fused_max_columns:
+        # the two-launch form beyond that (its 6-wave workgroups fill the SIMDs less evenly).  A few
+        # hundred frames give it under ten workgroups, each a serial loop over 960 channel taps;
+        # there the two-launch form, which splits that loop over workgroups, is faster again
+        # (reverse flow of one 3 s utterance: 1.38 -> 1.16 ms).
+        if self.fused and (self.fused_min_columns < B * T <= self.fused_max_columns or not native.SPLIT_SMALL_LAUNCHES):
             other = torch.empty_like(x)             # layers ping-pong: a layer's output may not land on its input
             for i in range(self.n_layers):
                 ic, rc = self.in_convs[i], self.rs_convs[i]

@@ -54,6 +54,7 @@ class ConvArgs(C.Structure):
         ("first", C.c_int32), ("hidden", C.c_int32), ("up_stride", C.c_int32),
         ("navg", C.c_float),
         ("precision", C.c_int32), ("narrow", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -145,6 +146,8 @@ def lib():
         L.vk_wn_layer.argtypes = [C.POINTER(WnArgs), C.c_void_p]
         L.vk_mrf_query.argtypes = [C.c_int, C.c_int, C.POINTER(TileInfo)]
         L.vk_mrf_stage.argtypes = [C.POINTER(MrfArgs), C.c_void_p]
+        L.vk_conv1d_workspace_bytes.argtypes = [C.POINTER(ConvArgs)]
+        L.vk_conv1d_workspace_bytes.restype = C.c_int64
         L.vk_sizeof_args.argtypes = [C.c_int]
         L.vk_sizeof_args.restype = C.c_size_t
         want = header_abi_version()
@@ -250,6 +253,25 @@ _EPI_NAMES = ["store", "resid", "resid_acc", "resid_avg", "gate", "wn_mid", "wn_
 _TILE_NAMES = ["m128", "m64", "m32", "pair"]
 
 
+SPLIT_SMALL_LAUNCHES = os.environ.get("VITS_AMD_SPLIT_K", "1") != "0"
+WS_COUNTER_BYTES = 65536
+WS_BYTES = WS_COUNTER_BYTES + (16 << 20)
+_workspaces = {}
+
+
+def workspace(device):
+    """Scratch for split channel loops, one per (device, stream): launches on different streams
+    may overlap in time and must not share arrival counters.  Zeroed once; every launch leaves the
+    counters zero."""
+    device = torch.device(device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.zeros(WS_BYTES // 4, dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
 def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue,
            bias=None, bias_bstride=0, res=None, out2=None, out3=None, aux=None, mask=None,
            act_in=False, in_slope=1.0, first=False, hidden=0, up_stride=0, navg=1.0):
@@ -291,11 +313,17 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     ti = tile_info(tile)
     blocks = -(-x.shape[2] // ti.time_tile) * -(-rows_all // ti.rows_per_block) * x.shape[0]
     a.narrow = int(precision == PREC_F32 and blocks < NARROW_BELOW_BLOCKS)
+    L = lib()
+    if precision == PREC_F32 and blocks < 256 and SPLIT_SMALL_LAUNCHES:
+        # far too few workgroups for 256 CUs: with scratch the library splits the channel loop
+        need = L.vk_conv1d_workspace_bytes(C.byref(a))
+        if need > 0:
+            ws = workspace(x.device)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     rows = c_out * up_stride if epilogue == EPI_UPSAMPLE else c_out
     flops = 2.0 * x.shape[0] * x.shape[2] * rows * c_in * taps
     family = (f"conv_{('mfma', 'bf16', 'split')[precision]}"
               f"[{_TILE_NAMES[tile]}{'n' if a.narrow else ''},{_EPI_NAMES[epilogue]},act={int(act_in)}]")
-    L = lib()
     sp = stream_ptr(x.device)
     detail = f"B{x.shape[0]} L{x.shape[2]} {c_in}->{rows} k{taps} d{dilation}"
     # algorithmic bytes: every activation view the launch reads or writes, once
