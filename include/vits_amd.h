@@ -156,6 +156,17 @@ int vk_conv1d(const vk_conv_args* a, void* stream);
 #define VK_WS_MAX_BYTES (VK_WS_COUNTER_BYTES + (16 << 20))
 int64_t vk_conv1d_workspace_bytes(const vk_conv_args* a);
 
+/* vk_conv1d with the split's scratch in a device array that is part of the library
+ * (VK_STATIC_SCRATCH_BYTES per GPU, held until the process ends) instead of a caller's
+ * workspace: `workspace` / `workspace_bytes` are ignored and the call never allocates or frees
+ * device memory.  No counterpart in the reference; it is for callers that cannot allocate:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * A launch that would need more scratch than the array holds is refused with VK_E_UNSUPPORTED
+ * (use vk_conv1d with a workspace).  All calls on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU (different streams) race; calls on one stream do not. */
+#define VK_STATIC_SCRATCH_BYTES (VK_WS_COUNTER_BYTES + (8 << 20))
+int vk_conv1d_static(const vk_conv_args* a, void* stream);
+
 /* ---- fused residual pair of a HiFi-GAN resblock ------------------------------------
  *   h   = conv1(lrelu(x, slope))            taps k, dilation d, padding (k-1)*d/2
  *   out = conv2(lrelu(h, slope)) + x        taps k, dilation 1, padding (k-1)/2

@@ -262,6 +262,47 @@ extern "C" int vk_conv1d(const vk_conv_args* a, void* stream)
     return conv1d_launch(a, d, grid, lds, vec, stream);
 }
 
+// ---- vk_conv1d_static: the split's scratch is a device array of the library ----
+// Zero when the code object is loaded; each GPU holds its own copy at its own address.  In host
+// code the array's name is only a handle for hipGetSymbolAddress: kernels, memsets and copies
+// take the address that call returns for the current device.
+static __device__ __align__(256) unsigned char scratch[VK_STATIC_SCRATCH_BYTES];
+static std::atomic<void*> g_scratch_addr[64];          // by device ordinal; null until first used there
+
+static int static_scratch(void** out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return vk_fail(VK_E_LAUNCH, hipGetErrorString(e));
+    if (dev < 0 || dev >= 64) return vk_fail(VK_E_UNSUPPORTED, "vk_conv1d_static: device ordinal beyond 63");
+    void* p = g_scratch_addr[dev].load(std::memory_order_acquire);
+    if (p == nullptr) {
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));     // this device's copy (the current device)
+        if (e != hipSuccess || p == nullptr)
+            return vk_fail(VK_E_LAUNCH, e != hipSuccess ? hipGetErrorString(e) : "vk_conv1d_static: no address for the scratch array");
+        g_scratch_addr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return VK_OK;
+}
+
+extern "C" int vk_conv1d_static(const vk_conv_args* a, void* stream)
+{
+    void* sp = nullptr;
+    int rc = static_scratch(&sp);
+    if (rc != VK_OK) return rc;
+    ConvDev d; dim3 grid; size_t lds = 0; int vec = 0; int64_t need = 0;
+    rc = derive(a, &d, &grid, &lds, &vec, sp, VK_STATIC_SCRATCH_BYTES, &need, false, "vk_conv1d_static");
+    if (rc != VK_OK) return rc;            // includes: more scratch needed than the array holds
+    if (d.ksplit > 1) {
+        // the arrival counters of this launch's output tiles start at zero whatever ran before
+        const size_t tiles = (size_t)d.n_tiles * d.n_rowblk * a->batch;
+        hipError_t e = hipMemsetAsync(sp, 0, tiles * sizeof(unsigned), (hipStream_t)stream);
+        if (e != hipSuccess) return vk_fail(VK_E_LAUNCH, hipGetErrorString(e));
+    }
+    return conv1d_launch(a, d, grid, lds, vec, stream);
+}
+
 static int conv1d_launch(const vk_conv_args* a, const ConvDev& d, dim3 grid, size_t lds, int vec, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;

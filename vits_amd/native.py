@@ -146,6 +146,7 @@ def lib():
         L.vk_wn_layer.argtypes = [C.POINTER(WnArgs), C.c_void_p]
         L.vk_mrf_query.argtypes = [C.c_int, C.c_int, C.POINTER(TileInfo)]
         L.vk_mrf_stage.argtypes = [C.POINTER(MrfArgs), C.c_void_p]
+        L.vk_conv1d_static.argtypes = [C.POINTER(ConvArgs), C.c_void_p]
         L.vk_conv1d_workspace_bytes.argtypes = [C.POINTER(ConvArgs)]
         L.vk_conv1d_workspace_bytes.restype = C.c_int64
         L.vk_sizeof_args.argtypes = [C.c_int]
@@ -274,8 +275,10 @@ def workspace(device):
 
 def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue,
            bias=None, bias_bstride=0, res=None, out2=None, out3=None, aux=None, mask=None,
-           act_in=False, in_slope=1.0, first=False, hidden=0, up_stride=0, navg=1.0):
-    """Enqueue one fused convolution on the current stream of ``x``'s device."""
+           act_in=False, in_slope=1.0, first=False, hidden=0, up_stride=0, navg=1.0, static_scratch=False):
+    """Enqueue one fused convolution on the current stream of ``x``'s device.  ``static_scratch``:
+    through ``vk_conv1d_static`` (a split channel loop keeps its partials in the library's own device
+    array: no workspace tensor, no allocation in the call)."""
     assert x.is_cuda, "the HIP path needs device tensors"
     a = ConvArgs()
     a.x, a.x_bstride, a.x_cstride = _view(x)
@@ -314,7 +317,7 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     blocks = -(-x.shape[2] // ti.time_tile) * -(-rows_all // ti.rows_per_block) * x.shape[0]
     a.narrow = int(precision == PREC_F32 and blocks < NARROW_BELOW_BLOCKS)
     L = lib()
-    if precision == PREC_F32 and blocks < 256 and SPLIT_SMALL_LAUNCHES:
+    if precision == PREC_F32 and blocks < 256 and SPLIT_SMALL_LAUNCHES and not static_scratch:
         # far too few workgroups for 256 CUs: with scratch the library splits the channel loop
         need = L.vk_conv1d_workspace_bytes(C.byref(a))
         if need > 0:
@@ -332,7 +335,9 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
         nbytes += 4.0 * res.numel()
     if out2 is not None and epilogue in (EPI_RESID_ACC, EPI_RESID_AVG, EPI_WN_MID, EPI_WN_LAST, EPI_SAMPLE):
         nbytes += 4.0 * out2.numel()
-    check(_timed(family, flops, nbytes, x.device, lambda: L.vk_conv1d(C.byref(a), sp), detail), "vk_conv1d")
+    entry = L.vk_conv1d_static if static_scratch else L.vk_conv1d
+    check(_timed(family, flops, nbytes, x.device, lambda: entry(C.byref(a), sp), detail),
+          "vk_conv1d_static" if static_scratch else "vk_conv1d")
 
 
 def resblock_pair(x, w1, bias1, w2, bias2, out, *, taps, dilation, epilogue, slope, acc=None, navg=1.0):
