@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import vits_oracle as O
-from vits_amd import synth
+from vits_amd import engine, synth
 from vits_amd.module.model_component.decoder import Decoder, ResNetBlock
 from vits_amd.module.model_component.flow import Flow, ResidualCouplingLayer
 from vits_amd.module.model_component.posterior_encoder import PosteriorEncoder
@@ -112,6 +112,22 @@ def test_flow_long_ragged(sd):
     for rev in (False, True):
         _check(fl(x.to(DEV), mask.to(DEV), g.to(DEV), reverse=rev), O.flow(x, mask, g, sd, reverse=rev),
                what=f"flow T=333 reverse={rev}")
+
+
+def test_flow_in_the_one_launch_layer_range(sd):
+    """5 x 900 frames: between the sizes where a WN layer runs as two launches (below 4096
+    columns, with the channel loop split over workgroups, and above 12288) the flow takes the
+    one-launch layer kernel."""
+    B, T = 5, 900
+    mask = synth.length_mask([900, 871, 640, 333, 12], T)
+    g = O.speaker_embed(torch.tensor([1, 50, 99, 7, 23]), sd)
+    x = synth.latent(SEED, "flow.mid", B, T)
+    fl = _load(Flow(), sd, "flow")
+    plan = fl.flows[0].wn.plan(torch.device(DEV)) if hasattr(fl.flows[0].wn, "plan") else None
+    if plan is not None and engine.precision_name() == "fp32":
+        assert plan.fused and plan.fused_min_columns < B * T <= plan.fused_max_columns
+    _check(fl(x.to(DEV), mask.to(DEV), g.to(DEV), reverse=True), O.flow(x, mask, g, sd, reverse=True),
+           what="flow 5 x 900 reverse")
 
 
 def test_decoder_golden_and_taps(sd, golden_dir):

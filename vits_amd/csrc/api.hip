@@ -196,15 +196,15 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     // (Diagnostic build: VK_XCD_MAP=0 / 1 forces it off / on for every precision.)
     static const int xcd_env = diag_env("VK_XCD_MAP", -1);
     d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : !split);
-    // A launch far too small for 256 CUs splits its channel loop over several workgroups per output
-    // tile (fp32 kernel only): as many as bring it to about one workgroup per CU, at least two
+    // A launch too small for 256 CUs splits its channel loop over several workgroups per output
+    // tile (fp32 kernel only): as many as bring it to about two workgroups per CU, at least two
     // chunks each, at most 8.  The partial accumulators and arrival counters live in scratch memory.
     d->ksplit = 1;
     d->ws = nullptr;
     *ws_need = 0;
     const int64_t wgs = (int64_t)d->n_tiles * d->n_rowblk * a->batch;
-    if (!bf16 && wgs < 128 && d->nchunk >= 4 && (query || ws != nullptr)) {
-        int k = (int)(256 / wgs);
+    if (!bf16 && wgs < 256 && d->nchunk >= 4 && (query || ws != nullptr)) {
+        int k = (int)(512 / wgs);
         if (k > d->nchunk / 2) k = d->nchunk / 2;
         if (k > 8) k = 8;
         if (k > 1) {

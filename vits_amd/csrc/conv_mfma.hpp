@@ -726,24 +726,34 @@ conv_mfma_kernel(const ConvDev d)
         // register is 256 contiguous bytes); the workgroup that finds the tile's counter at
         // ksplit - 1 is the last, adds the partials in split order (its own included, so the sum
         // does not depend on who arrives last), clears the counter for the next launch and goes on.
+        // The partials travel as device-scope accesses (written through to memory, read past the
+        // caches) and a workgroup counts itself in only once its own stores have completed, so no
+        // cache-wide write-back or invalidate is needed: a device-scope fence costs this launch
+        // about 40 us on the 8-XCD part, more than the split saves.
         constexpr int PER_WAVE = A_REP * B_REP * 16 * 64;
         const int tile_id = (b * d.n_tiles + tile) * d.n_rowblk + rowblk;
         unsigned* counter = reinterpret_cast<unsigned*>(d.ws) + tile_id;
-        float* part = d.ws + VK_WS_COUNTER_BYTES / 4 + ((size_t)tile_id * d.ksplit * NW + w) * PER_WAVE + lane;
-        float* mine = part + (size_t)split * NW * PER_WAVE;
+        unsigned* part = reinterpret_cast<unsigned*>(d.ws) + VK_WS_COUNTER_BYTES / 4
+                       + ((size_t)tile_id * d.ksplit * NW + w) * PER_WAVE + lane;
+        unsigned* mine = part + (size_t)split * NW * PER_WAVE;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m)
 #pragma unroll
             for (int n = 0; n < B_REP; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mine[((m * B_REP + n) * 16 + r) * 64] = acc[m][n][r];
-        __threadfence();                               // partials visible device-wide before the count
-        __syncthreads();                               // (also: every wave is done with the staged tiles)
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[m][n][r];       // (a bit_cast straight from the vector element stores element 0)
+                    __hip_atomic_store(mine + ((m * B_REP + n) * 16 + r) * 64, __builtin_bit_cast(unsigned, v),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        // this wave's write-through stores have completed (a workgroup-scope fence does not wait for them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // ... every wave's (and every wave is done with the staged tiles)
         unsigned* arrived = reinterpret_cast<unsigned*>(lds);
-        if (threadIdx.x == 0) *arrived = atomicAdd(counter, 1u);
+        if (threadIdx.x == 0)
+            *arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*arrived != (unsigned)(d.ksplit - 1)) return;
-        __threadfence();                               // the other workgroups' partials, not stale lines
 #pragma unroll
         for (int m = 0; m < A_REP; ++m)
 #pragma unroll
@@ -751,16 +761,17 @@ conv_mfma_kernel(const ConvDev d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
         for (int sp = 0; sp < d.ksplit; ++sp) {
-            const float* src = part + (size_t)sp * NW * PER_WAVE;
+            const unsigned* src = part + (size_t)sp * NW * PER_WAVE;
 #pragma unroll
             for (int m = 0; m < A_REP; ++m)
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        acc[m][n][r] += src[((m * B_REP + n) * 16 + r) * 64];
+                        acc[m][n][r] += __builtin_bit_cast(float, __hip_atomic_load(src + ((m * B_REP + n) * 16 + r) * 64,
+                                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
-        if (threadIdx.x == 0) *counter = 0u;
+        if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     conv_epilogue<A_REP, B_REP, EPI>(d, acc, b, t0, mt0, wn, half, l31);
 }

@@ -29,8 +29,8 @@ from ...packing import pair_row_order
 class WNPlan:
     """Packed weights of one WN stack on one device."""
 
-    fused_max_columns = 16384
-    fused_min_columns = 448      # below: two launches per layer, each with its channel loop split over workgroups
+    fused_max_columns = 12288
+    fused_min_columns = 4096     # below: two launches per layer, each with its channel loop split over workgroups
 
     def __init__(self, wn: "WN", device):
         H, n = wn.hidden_channels, wn.n_resblocks
@@ -75,12 +75,11 @@ class WNPlan:
         if out is None:
             out = torch.empty_like(x)
         cstride = cond.stride(0)
-        # Measured on the MI355X: the one-launch layer wins for small batches (fewer dependent
-        # launches: 6.85 -> 6.57 ms for one 10 s utterance), ties at 16 x 862 frames, and loses to
-        # the two-launch form beyond that (its 6-wave workgroups fill the SIMDs less evenly).  A few
-        # hundred frames give it under ten workgroups, each a serial loop over 960 channel taps;
-        # there the two-launch form, which splits that loop over workgroups, is faster again
-        # (reverse flow of one 3 s utterance: 1.38 -> 1.16 ms).
+        # Measured on the MI355X (reverse flow, batch x 862 frames, one-launch layer / two launches):
+        # 1: 1.37 / 0.87 ms, 4: 1.39 / 1.14, 8: 1.42 / 1.78, 16: 2.49 / 2.37.  A few thousand frames
+        # give the one-launch layer a few dozen workgroups, each a serial loop over 960 channel taps,
+        # while the two-launch form splits that loop over workgroups; in between the one-launch
+        # layer's fewer dependent launches win; beyond, its 6-wave workgroups fill the SIMDs less evenly.
         if self.fused and (self.fused_min_columns < B * T <= self.fused_max_columns or not native.SPLIT_SMALL_LAUNCHES):
             other = torch.empty_like(x)             # layers ping-pong: a layer's output may not land on its input
             for i in range(self.n_layers):

@@ -256,7 +256,7 @@ _TILE_NAMES = ["m128", "m64", "m32", "pair"]
 
 SPLIT_SMALL_LAUNCHES = os.environ.get("VITS_AMD_SPLIT_K", "1") != "0"
 WS_COUNTER_BYTES = 65536
-WS_BYTES = WS_COUNTER_BYTES + (16 << 20)
+WS_BYTES = WS_COUNTER_BYTES + (32 << 20)     # VK_WS_MAX_BYTES: at most 512 partial tiles of 64 KiB
 _workspaces = {}
 
 
