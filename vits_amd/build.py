@@ -49,7 +49,8 @@ def _compile(src: str, force: bool, hdr_mtime: float, diag: bool = False) -> str
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_mtime)):
         return obj
-    cmd = [HIPCC, *FLAGS, *(["-DVK_DIAG"] if diag else []), "-c", path, "-o", obj]
+    extra = os.environ.get("VITS_AMD_HIPCC_FLAGS", "").split() if diag else []      # diagnostic experiments only
+    cmd = [HIPCC, *FLAGS, *(["-DVK_DIAG"] if diag else []), *extra, "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

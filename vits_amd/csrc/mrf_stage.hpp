@@ -32,6 +32,16 @@
 #include "conv_bf16.hpp"
 #include "resblock_pair_bf16.hpp"
 
+// Diagnostic build only (-DVK_DIAG -DVK_MRF_ABL=n, results invalid): timing experiments that take a
+// part of the kernel away.  1: no activation / rounding / LDS store of a conv's result, 2: no
+// barriers, 4: no matrix instructions.
+#if defined(VK_DIAG) && defined(VK_MRF_ABL)
+constexpr int kMrfAbl = VK_MRF_ABL;
+#else
+constexpr int kMrfAbl = 0;
+#endif
+#define VK_MRF_SYNC() do { if (!(kMrfAbl & 2)) __syncthreads(); } while (0)
+
 constexpr int VK_MRF_HALO   = 64;
 constexpr int VK_MRF_GUARD  = 32;                           // addressable columns on either side of an image
 
@@ -107,6 +117,8 @@ mrf_stage_bf16_kernel(const MrfDev q)
     bool inside[NT];                            // this lane's column of tile n lies in [0, L)
 #pragma unroll
     for (int n = 0; n < NT; ++n) inside[n] = (tw + 32 * n >= 0) && (tw + 32 * n < L);
+    // most windows lie wholly inside the sequence: their workgroups skip the per-element selects
+    const bool edge = (t0 - q.halo < 0) || (t0 - q.halo + WIN > L);     // workgroup-uniform
 
     // weight fragments of the conv about to run (first tap), requested one conv ahead
     auto wfrag = [&](const void* wp, int groups) {
@@ -120,7 +132,9 @@ mrf_stage_bf16_kernel(const MrfDev q)
 
     // accumulator-layout register r of a lane is channel 32*wm + (r & 3) + 8*(r >> 2) + 4*half;
     // four consecutive registers are four consecutive channels: one 8-byte store into an image
-    auto put_image = [&](char* img, const f32x16 (&v)[NT], bool act_only_inside) {
+    auto put_image_as = [&](char* img, const f32x16 (&v)[NT], auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        if (kMrfAbl & 1) return;
         char* dst = img + (VK_MRF_GUARD + col0) * PITCH + (wm * 32 + 4 * half) * 2;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -131,13 +145,19 @@ mrf_stage_bf16_kernel(const MrfDev q)
                 for (int e = 0; e < 4; e += 2) {
                     float v0 = vk_lrelu(v[n][4 * g + e], p.slope);
                     float v1 = vk_lrelu(v[n][4 * g + e + 1], p.slope);
-                    if (act_only_inside) { v0 = inside[n] ? v0 : 0.0f; v1 = inside[n] ? v1 : 0.0f; }
+                    if (MASKED) { v0 = inside[n] ? v0 : 0.0f; v1 = inside[n] ? v1 : 0.0f; }
                     const f32x2 pr = {v0, v1};
                     const bf16x2 c2 = __builtin_convertvector(pr, bf16x2);
                     o[e] = c2[0]; o[e + 1] = c2[1];
                 }
                 *reinterpret_cast<bf16x4*>(dst + n * 32 * PITCH + g * 16) = o;
             }
+    };
+    // two copies of the code, chosen by a workgroup-uniform branch: the selects cost a vector
+    // instruction per element in a phase that is all vector instructions
+    auto put_image = [&](char* img, const f32x16 (&v)[NT], bool act_only_inside) {
+        if (act_only_inside && edge) put_image_as(img, v, std::true_type{});
+        else                         put_image_as(img, v, std::false_type{});
     };
 
     // one convolution of this wave's three tiles: bias, then every chunk's taps out of an image
@@ -164,6 +184,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
         }
         const int pad = ((taps - 1) >> 1) * dilation;
         const char* base = img + (VK_MRF_GUARD + col0 - pad) * PITCH + half * 16;
+        if (kMrfAbl & 4) return;
         for (int chunk = 0; chunk < NCH; ++chunk)
             bf16_taps<1, NT, KS, PITCH, PF>(acc, a, aptr, base + chunk * 64, taps, dilation * PITCH);
     };
@@ -193,16 +214,16 @@ mrf_stage_bf16_kernel(const MrfDev q)
             }
         }
         put_image(img_a, xr, false);
-        __syncthreads();
+        VK_MRF_SYNC();
 
         const int taps = p.taps[blk];
         for (int j = 0; j < p.n_pairs; ++j) {
             const int ci = (blk * p.n_pairs + j) * 2;
             // ---- h = conv1(lrelu(x_r)), dilated ----
             conv(img_a, ci, p.w1[blk][j], q.groups[blk], taps, p.dilation[blk][j], p.w2[blk][j], q.groups[blk]);
-            if (!TWO) __syncthreads();          // every wave has read what the next lines overwrite
+            if (!TWO) VK_MRF_SYNC();          // every wave has read what the next lines overwrite
             put_image(img_h, acc[0], true);
-            __syncthreads();
+            VK_MRF_SYNC();
             // ---- x_r = conv2(lrelu(h)) + x_r ----
             const bool last_pair = j + 1 == p.n_pairs;
             const bool last_conv = last_pair && blk + 1 == p.n_blocks;
@@ -212,11 +233,17 @@ mrf_stage_bf16_kernel(const MrfDev q)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xr[n][r] = inside[n] ? acc[0][n][r] + xr[n][r] : 0.0f;
+                for (int r = 0; r < 16; ++r) xr[n][r] = acc[0][n][r] + xr[n][r];
+            if (edge) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xr[n][r] = inside[n] ? xr[n][r] : 0.0f;
+            }
             if (!last_pair) {
-                if (!TWO) __syncthreads();
+                if (!TWO) VK_MRF_SYNC();
                 put_image(img_a, xr, false);
-                __syncthreads();
+                VK_MRF_SYNC();
             }
         }
         if (SUM) {
@@ -225,7 +252,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tot[n][r] += xr[n][r];
         }
-        if (!TWO && blk + 1 < p.n_blocks) __syncthreads();     // the next resblock's input replaces h
+        if (!TWO && blk + 1 < p.n_blocks) VK_MRF_SYNC();     // the next resblock's input replaces h
     }
 
     // ---- out = sum / n_blocks for the window's output columns ----
