@@ -139,8 +139,7 @@ def test_front_graph_draws_fresh_duration_noise():
     w_graph = w_graph.clone().cpu()
     torch.manual_seed(11)
     _, _, _, w_eager, _ = gen._token_stage(ids, lens, spk, None, 3, 0.8)
-    d = (w_graph - w_eager.cpu()).abs()
-    assert d.max().item() <= 1.0 and int((d > 0).sum()) <= 1     # a duration on an integer boundary may move by one
+    assert torch.equal(w_graph, w_eager.cpu())
     wav = gen.text_to_speech(ids, lens, spk, length_scale=3)
     assert torch.isfinite(wav).all() and wav.shape[2] % 256 == 0
 

@@ -227,10 +227,8 @@ def test_graph_replay_matches_eager(sd):
 
 def test_front_half_graph_replay_matches_eager():
     """Token-level half (text encoder + duration predictor, stock PyTorch kernels) captured into
-    a HIP graph and replayed with other tokens, speaker and noise: same token-level prior and
-    durations as the eager path.  The library kernels PyTorch picks may differ between a captured
-    and an eager run, so values are compared to 1e-5 and a duration may move by one frame where
-    exp(logw) sits on an integer boundary."""
+    a HIP graph and replayed with other tokens, speaker and noise: the same kernels in the same
+    order as the eager path, so the token-level prior and the durations are identical."""
     from vits_amd.module.vits_generator import VitsGenerator
     gen = VitsGenerator(40, 100)
     gen.load_state_dict(synth.full_state_dict(gen.state_dict(), SEED), strict=True)
@@ -247,20 +245,20 @@ def test_front_half_graph_replay_matches_eager():
         got = gen._token_stage_graphed(ids, lens, spk, nw, 3, 0.8)
         for name, a, b in zip(("m_p", "logs_p", "text_mask", "w_ceil", "g"), got, ref):
             assert a.shape == b.shape, name
-            if name == "w_ceil":
-                d = (a - b).abs()
-                assert d.max().item() <= 1.0 and int((d > 0).sum()) <= 1, name
-            else:
-                assert (a - b).abs().max().item() <= 1e-5, name
+            assert torch.equal(a, b), name
     assert len(gen._front_graphs) == 1
-    gen.use_front_graph = True
-    try:
-        ids, spk, nw = cases[0]
+    ids, spk, nw = cases[0]
+    frames = int(eager[0][3].sum().item())
+    for on in (True, False):
+        gen.use_front_graph = on
         wav = gen.text_to_speech(ids, lens, spk, length_scale=3, noise_w=nw)
-        frames = int(eager[0][3].sum().item())
-        assert torch.isfinite(wav).all() and abs(wav.shape[2] // 256 - frames) <= 1
-    finally:
-        gen.use_front_graph = False
+        assert torch.isfinite(wav).all() and wav.shape[2] // 256 == frames
+    # a move of the weights (here: a round trip through the host) retires the captured graph
+    gen.use_front_graph = True
+    gen.text_encoder.to("cpu")
+    gen.text_encoder.to(DEV)
+    got = gen._token_stage_graphed(ids, lens, spk, nw, 3, 0.8)
+    assert all(torch.equal(a, b) for a, b in zip(got, eager[0]))
 
 
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (2, 5)])

@@ -126,10 +126,12 @@ class VitsGenerator(HotPathGenerator):
 
     # The token-level half (text encoder, duration predictor) is some 400 tiny stock-PyTorch
     # launches whose cost is host launch time (about 7.5 ms for one sentence against about 1.5 ms
-    # of GPU work).  With ``use_front_graph`` it is captured once per (batch, tokens, scales)
-    # into a HIP graph and replayed; everything after the durations has data-dependent shapes
-    # and stays eager.  VITS_AMD_FRONT_GRAPH=1 turns it on for every instance.
-    use_front_graph = os.environ.get("VITS_AMD_FRONT_GRAPH", "0") == "1"
+    # of GPU work).  It is captured once per (batch, tokens, scales) into a HIP graph and
+    # replayed (bit-identical to the eager run: same kernels, same order); everything after the
+    # durations has data-dependent shapes and stays eager.  VITS_AMD_FRONT_GRAPH=0, or
+    # ``use_front_graph = False`` on an instance, keeps this half eager too.
+    use_front_graph = os.environ.get("VITS_AMD_FRONT_GRAPH", "1") != "0"
+    max_front_graphs = 16           # captured shapes kept per instance (least recently used goes first)
 
     def _token_stage(self, text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w):
         """Lines 169-176 of ``text_to_speech``: token-level prior and sampled durations."""
@@ -139,6 +141,12 @@ class VitsGenerator(HotPathGenerator):
                                                   noise_scale=noise_scale_w, noise=noise_w)
         w_ceil = torch.ceil(torch.exp(logw) * text_mask * length_scale)
         return m_p, logs_p, text_mask, w_ceil, g
+
+    def _front_weights_key(self):
+        """Where the captured kernels read their weights from: a graph is only good while the
+        parameters stay in the storage they had at capture (in-place loads keep it, .to() does not)."""
+        mods = (self.text_encoder, self.stochastic_duration_predictor, self.speaker_embedding)
+        return hash(tuple(p.data_ptr() for m in mods for p in m.parameters()))
 
     def _token_stage_graphed(self, text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w):
         from ..graphs import GraphedCall
@@ -150,12 +158,23 @@ class VitsGenerator(HotPathGenerator):
             # draw as the eager path (CPU generator, then copied), fed to the graph as an input.
             noise_w = torch.randn(text_padded.size(0), 2, text_padded.size(1)).to(
                 device=text_padded.device, dtype=torch.float32)
-        key = (tuple(text_padded.shape), str(text_padded.device), float(length_scale), float(noise_scale_w))
-        call = self._front_graphs.get(key)
+        if torch.cuda.is_current_stream_capturing():        # inside somebody else's capture: no graph of our own
+            return self._token_stage(text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w)
+        key = (tuple(text_padded.shape), str(text_padded.device), float(length_scale), float(noise_scale_w),
+               self._front_weights_key())
+        call = self._front_graphs.pop(key, None)
         if call is None:
-            call = GraphedCall(lambda t, l, s, n: self._token_stage(t, l, s, n, length_scale, noise_scale_w),
-                               text_padded, text_lengths, speaker_id, noise_w)
-            self._front_graphs[key] = call
+            try:
+                call = GraphedCall(lambda t, l, s, n: self._token_stage(t, l, s, n, length_scale, noise_scale_w),
+                                   text_padded, text_lengths, speaker_id, noise_w)
+            except Exception as e:                           # capture refused (allocator, library): stay eager
+                import warnings
+                warnings.warn(f"token-level graph capture failed ({type(e).__name__}: {e}); running it eagerly")
+                self.use_front_graph = False
+                return self._token_stage(text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w)
+            while len(self._front_graphs) >= self.max_front_graphs:
+                self._front_graphs.pop(next(iter(self._front_graphs)))
+        self._front_graphs[key] = call                       # most recently used last
         m_p, logs_p, text_mask, w_ceil, g = call(text_padded, text_lengths, speaker_id, noise_w)
         return m_p, logs_p, text_mask, w_ceil, g.clone()     # g outlives this call; the rest is consumed at once
 
