@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: time the fused resblock pair of one shape (needs a GPU).
-  pair_probe.py C K DIL B L [bf16|fp32] [iterations]"""
+  pair_probe.py C K DIL B L [bf16|fp32] [iterations] [diagnostic library]"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -9,6 +9,9 @@ from vits_amd import native, packing
 C, K, DIL, B, L = (int(a) for a in sys.argv[1:6])
 prec = sys.argv[6] if len(sys.argv) > 6 else "bf16"
 n = int(sys.argv[7]) if len(sys.argv) > 7 else 20
+if len(sys.argv) > 8:                      # a diagnostic build: path of the library
+    native.DIAG_LIB_PATH = sys.argv[8]
+    native.use_diagnostic_library()
 dev = torch.device("cuda:0")
 P = native.PREC_BF16 if prec == "bf16" else native.PREC_F32
 pi = native.pair_info(C, P)

@@ -93,6 +93,13 @@ struct Bf16Stager {
 #define VK_BF16_PF 2
 #endif
 constexpr int VK_PF = VK_BF16_PF;
+// Diagnostic build only (-DVK_DIAG -DVK_BF16_ABL=n, results invalid): 1 = the tap loop fetches no
+// weight fragments, 2 = it reads no B fragments from LDS.
+#if defined(VK_DIAG) && defined(VK_BF16_ABL)
+constexpr int kBf16Abl = VK_BF16_ABL;
+#else
+constexpr int kBf16Abl = 0;
+#endif
 
 // a[i] = fragments of tap i of the stream `aptr` points into (i < VK_PF)
 template <int KS, int A_REP, int PF = VK_PF>
@@ -126,13 +133,14 @@ __device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
-            for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = aptr[m][64 * (KS * PF + k)];
+            for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = (kBf16Abl & 1) ? a[0][k][m] : aptr[m][64 * (KS * PF + k)];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             bf16x8 bn[B_REP];
 #pragma unroll
             for (int n = 0; n < B_REP; ++n)
-                bn[n] = (k + 1 < KS) ? *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH + (k + 1) * 32)
+                bn[n] = (kBf16Abl & 2) ? bf[n]
+                      : (k + 1 < KS) ? *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH + (k + 1) * 32)
                                      : *reinterpret_cast<const bf16x8*>(bt_next + n * 32 * PITCH);
 #pragma unroll
             for (int m = 0; m < A_REP; ++m)
