@@ -151,9 +151,9 @@ int64_t     vk_conv1d_lds_bytes(const vk_conv_args* a);
 int vk_conv1d(const vk_conv_args* a, void* stream);
 
 /* Bytes of `workspace` this launch would use (counters included), 0 if it does not split, or a
- * negative VK_E_* code.  A launch splits when it has fewer than 256 workgroups and at least 4
+ * negative VK_E_* code.  A launch splits when it has fewer than 512 workgroups and at least 4
  * channel chunks; never more than VK_WS_MAX_BYTES. */
-#define VK_WS_MAX_BYTES (VK_WS_COUNTER_BYTES + (32 << 20))
+#define VK_WS_MAX_BYTES (VK_WS_COUNTER_BYTES + (64 << 20))
 int64_t vk_conv1d_workspace_bytes(const vk_conv_args* a);
 
 /* vk_conv1d with the split's scratch in a device array that is part of the library
@@ -164,7 +164,7 @@ int64_t vk_conv1d_workspace_bytes(const vk_conv_args* a);
  * A launch that would need more scratch than the array holds is refused with VK_E_UNSUPPORTED
  * (use vk_conv1d with a workspace).  All calls on one GPU share that GPU's array: calls that
  * overlap in time on one GPU (different streams) race; calls on one stream do not. */
-#define VK_STATIC_SCRATCH_BYTES (VK_WS_COUNTER_BYTES + (16 << 20))
+#define VK_STATIC_SCRATCH_BYTES (VK_WS_COUNTER_BYTES + (32 << 20))
 int vk_conv1d_static(const vk_conv_args* a, void* stream);
 
 /* ---- fused residual pair of a HiFi-GAN resblock ------------------------------------

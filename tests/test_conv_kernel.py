@@ -574,7 +574,7 @@ def test_fused_mrf_stage_rejects_bad_arguments():
 
 # ---- split channel loop of launches too small to fill the GPU (fp32 kernel, scratch workspace) ----
 @pytest.mark.parametrize("cin,cout,k,dil,B,L", [
-    (256, 256, 11, 1, 1, 2064),      # decoder stage 1 of a 3 s utterance: 66 workgroups, 7 splits
+    (256, 256, 11, 1, 1, 2064),      # decoder stage 1 of a 3 s utterance: 66 workgroups, 8 splits
     (256, 256, 3, 5, 1, 70),
     (192, 512, 7, 1, 1, 258),
     (512, 256, 7, 1, 2, 33),
@@ -622,8 +622,8 @@ def test_split_channel_loop_workspace_contract():
     a.taps, a.dilation, a.pad, a.tile, a.epilogue, a.narrow = k, 1, 3, choose_tile(cout), native.EPI_STORE, 1
     L_ = native.lib()
     need = L_.vk_conv1d_workspace_bytes(C.byref(a))
-    # 33 tiles x 2 row blocks = 66 workgroups -> 7 splits of a 128 x 64 tile
-    assert need == native.WS_COUNTER_BYTES + 66 * 7 * 128 * 64 * 4
+    # 33 tiles x 2 row blocks = 66 workgroups -> 8 splits of a 128 x 64 tile
+    assert need == native.WS_COUNTER_BYTES + 66 * 8 * 128 * 64 * 4
     sp = native.stream_ptr(x.device)
     assert L_.vk_conv1d(C.byref(a), sp) == 0           # no workspace: runs unsplit
     small = torch.zeros(need // 4 - 1, device=DEV)

@@ -197,14 +197,16 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     static const int xcd_env = diag_env("VK_XCD_MAP", -1);
     d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : !split);
     // A launch too small for 256 CUs splits its channel loop over several workgroups per output
-    // tile (fp32 kernel only): as many as bring it to about two workgroups per CU, at least two
-    // chunks each, at most 8.  The partial accumulators and arrival counters live in scratch memory.
+    // tile (fp32 kernel only): as many as bring it to about four workgroups per CU, at least two
+    // chunks each, at most 8 (one utterance of 3 s, decoder: 2.07 ms at two per CU, 1.96 ms at four).
+    // (Diagnostic build: VK_SPLITK_BELOW / VK_SPLITK_TARGET move the two thresholds.)  The partial accumulators and arrival counters live in scratch memory.
     d->ksplit = 1;
     d->ws = nullptr;
     *ws_need = 0;
     const int64_t wgs = (int64_t)d->n_tiles * d->n_rowblk * a->batch;
-    if (!bf16 && wgs < 256 && d->nchunk >= 4 && (query || ws != nullptr)) {
-        int k = (int)(512 / wgs);
+    static const int sk_below = diag_env("VK_SPLITK_BELOW", 512), sk_target = diag_env("VK_SPLITK_TARGET", 1024);
+    if (!bf16 && wgs < sk_below && d->nchunk >= 4 && (query || ws != nullptr)) {
+        int k = (int)(sk_target / wgs);
         if (k > d->nchunk / 2) k = d->nchunk / 2;
         if (k > 8) k = 8;
         if (k > 1) {

@@ -256,7 +256,7 @@ _TILE_NAMES = ["m128", "m64", "m32", "pair"]
 
 SPLIT_SMALL_LAUNCHES = os.environ.get("VITS_AMD_SPLIT_K", "1") != "0"
 WS_COUNTER_BYTES = 65536
-WS_BYTES = WS_COUNTER_BYTES + (32 << 20)     # VK_WS_MAX_BYTES: at most 512 partial tiles of 64 KiB
+WS_BYTES = WS_COUNTER_BYTES + (64 << 20)     # VK_WS_MAX_BYTES: at most 1024 partial tiles of 64 KiB
 _workspaces = {}
 
 
@@ -317,7 +317,7 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     blocks = -(-x.shape[2] // ti.time_tile) * -(-rows_all // ti.rows_per_block) * x.shape[0]
     a.narrow = int(precision == PREC_F32 and blocks < NARROW_BELOW_BLOCKS)
     L = lib()
-    if precision == PREC_F32 and blocks < 256 and SPLIT_SMALL_LAUNCHES and not static_scratch:
+    if precision == PREC_F32 and blocks < 512 and SPLIT_SMALL_LAUNCHES and not static_scratch:
         # far too few workgroups for 256 CUs: with scratch the library splits the channel loop
         need = L.vk_conv1d_workspace_bytes(C.byref(a))
         if need > 0:
