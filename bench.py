@@ -156,7 +156,7 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+        raise SystemExit(f"bench.py (rank {rank} of {world}) needs an MI355X (no CPU fallback for the HIP path)")
     if args.share_gpu:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)

@@ -118,7 +118,10 @@ def test_bench_parent_spawns_ranks_before_touching_the_gpu(tmp_path):
     if torch.cuda.is_available():
         return                                                      # on a GPU box the run itself is the test
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs an MI355X") == 2
+    # (the launcher stops the other rank as soon as one has failed, so one or both get to say it)
+    import re
+    said = re.findall(r"bench\.py \(rank (\d) of 2\) needs an MI355X", r.stderr)
+    assert 1 <= len(said) <= 2 and set(said) <= {"0", "1"}
 
 
 def test_bench_rejects_a_world_size_that_contradicts_gpus():
