@@ -237,7 +237,7 @@ typedef struct {
     float* out;           int64_t out_bstride; int64_t out_cstride;
     int32_t batch, channels, length;
     int32_t n_blocks, n_pairs;
-    int32_t taps[VK_MRF_MAX_BLOCKS];                                   /* odd */
+    int32_t taps[VK_MRF_MAX_BLOCKS];                                   /* odd, >= 3 */
     int32_t dilation[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
     const void*  w1[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
     const float* bias1[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];

@@ -559,7 +559,7 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
     int halo = 0;
     for (int r = 0; r < a->n_blocks; ++r) {
         const int k = a->taps[r];
-        if (k < 1 || !(k & 1)) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: taps must be odd");
+        if (k < 3 || !(k & 1)) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: taps must be odd and at least 3");
         int reach = 0;
         for (int j = 0; j < a->n_pairs; ++j) {
             if (a->dilation[r][j] < 1) return vk_fail(VK_E_ARG, "vk_mrf_stage: dilation < 1");

@@ -87,7 +87,7 @@ struct Bf16Stager {
 };
 
 // Taps of weight fragments in flight ahead of the matrix instructions that consume them.  A tap
-// of a 32-channel chunk is only 2 * A_REP * B_REP matrix instructions (200-260 cycles), less than
+// of a 32-channel chunk is only 2 * A_REP * B_REP matrix instructions (250-500 cycles), about what
 // an L2 hit takes on a busy chip, so fragments are requested two taps ahead.
 #ifndef VK_BF16_PF
 #define VK_BF16_PF 2
@@ -101,7 +101,7 @@ constexpr int kBf16Abl = VK_BF16_ABL;
 constexpr int kBf16Abl = 0;
 #endif
 
-// a[i] = fragments of tap i of the stream `aptr` points into (i < VK_PF)
+// The weight fragments of a wave: a[i] holds tap i of the stream `aptr` points into (i < PF).
 template <int KS, int A_REP, int PF = VK_PF>
 __device__ __forceinline__ void bf16_wload(bf16x8 (&a)[PF][KS][A_REP], const bf16x8* (&aptr)[A_REP])
 {
@@ -113,27 +113,35 @@ __device__ __forceinline__ void bf16_wload(bf16x8 (&a)[PF][KS][A_REP], const bf1
             for (int m = 0; m < A_REP; ++m) a[i][k][m] = aptr[m][64 * (KS * i + k)];
 }
 
-// The k-loop over one resident chunk (KS matrix instructions per tap): weights fetched VK_PF taps
-// ahead (PF), B fragments of the next k-step read before the current k-step's MFMAs are issued.
-// `base` is this lane's fragment address for tap 0 / k-step 0 / column tile 0.  The weight stream
-// runs on linearly past the chunk (next chunk, next row tile or the zero groups that end a packed
-// tensor), so a[] arrives holding the current tap and leaves holding the next chunk's first.
+// The k-loop over one resident chunk (KS matrix instructions per tap).  B fragments of the next
+// k-step are read before the current k-step's MFMAs are issued; `base` is this lane's fragment
+// address for tap 0 / k-step 0 / column tile 0.  Weights: the loop runs PF taps per iteration,
+// tap i out of a[i]; as soon as the matrix instructions of a k-step have been issued its registers
+// are refilled in place with the same k-step PF taps further on, so every fragment has PF whole
+// taps to arrive and the loop copies no register.  A remainder of taps % PF taps follows, after
+// which the fragments are moved back so that a[0] is again the next tap (once per chunk).  The
+// stream runs on linearly past the chunk (next chunk, next row tile or the zero groups that end a
+// packed tensor); with `use_cont` (set for a convolution's last chunk) it continues in the stream
+// `cont` instead (the next convolution's weights), whose first PF taps a[] then holds on return.
 template <int A_REP, int B_REP, int KS, int PITCH, int PF = VK_PF>
 __device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&a)[PF][KS][A_REP],
-                                          const bf16x8* (&aptr)[A_REP], const char* base, int taps, int tap_step)
+                                          const bf16x8* (&aptr)[A_REP], const char* base, int taps, int tap_step,
+                                          const bf16x8* (&cont)[A_REP], bool use_cont)
 {
     const char* bt = base;
     bf16x8 bf[B_REP];
 #pragma unroll
     for (int n = 0; n < B_REP; ++n) bf[n] = *reinterpret_cast<const bf16x8*>(bt + n * 32 * PITCH);
-#pragma unroll 1
-    for (int tap = 0; tap < taps; ++tap) {
+
+    // one tap out of ring slot S; aptr points at this tap's fragments
+    auto one_tap = [&](auto slot_tag, int tap) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
         const char* bt_next = (tap + 1 < taps) ? bt + tap_step : base;     // chunk end: harmless re-read
-        bf16x8 a_nxt[KS][A_REP];
+        const int ahead = tap + PF - taps;              // >= 0: what this slot holds next lies past the chunk
+        const bf16x8* src[A_REP];
 #pragma unroll
-        for (int k = 0; k < KS; ++k)
-#pragma unroll
-            for (int m = 0; m < A_REP; ++m) a_nxt[k][m] = (kBf16Abl & 1) ? a[0][k][m] : aptr[m][64 * (KS * PF + k)];
+        for (int m = 0; m < A_REP; ++m)
+            src[m] = (use_cont && ahead >= 0) ? cont[m] + 64 * KS * ahead : aptr[m] + 64 * KS * PF;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             bf16x8 bn[B_REP];
@@ -146,22 +154,47 @@ __device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&
             for (int m = 0; m < A_REP; ++m)
 #pragma unroll
                 for (int n = 0; n < B_REP; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][k][m], bf[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][k][m], bf[n], acc[m][n], 0, 0, 0);
 #pragma unroll
             for (int n = 0; n < B_REP; ++n) bf[n] = bn[n];
+            if (!(kBf16Abl & 1)) {
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) a[S][k][m] = src[m][64 * k];
+            }
         }
         bt = bt_next;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) aptr[m] += 64 * KS;
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-#pragma unroll
-            for (int m = 0; m < A_REP; ++m) {
-#pragma unroll
-                for (int i = 0; i + 1 < PF; ++i) a[i][k][m] = a[i + 1][k][m];
-                a[PF - 1][k][m] = a_nxt[k][m];
-            }
+    };
+
+    int tap = 0;
+#pragma unroll 1
+    for (; tap + PF <= taps; tap += PF) {
+        one_tap(std::integral_constant<int, 0>{}, tap);
+        if constexpr (PF > 1) one_tap(std::integral_constant<int, 1>{}, tap + 1);
+        if constexpr (PF > 2) one_tap(std::integral_constant<int, 2>{}, tap + 2);
     }
+    if constexpr (PF > 1) {
+        static_assert(PF == 2, "the remainder below is written for a ring of two");
+        if (tap < taps) {                               // one tap left over: use slot 0, then swap the slots
+            one_tap(std::integral_constant<int, 0>{}, tap);
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int m = 0; m < A_REP; ++m) {
+                    const bf16x8 t = a[0][k][m];
+                    a[0][k][m] = a[1][k][m];
+                    a[1][k][m] = t;
+                }
+        }
+    }
+}
+
+template <int A_REP, int B_REP, int KS, int PITCH, int PF = VK_PF>
+__device__ __forceinline__ void bf16_taps(f32x16 (&acc)[A_REP][B_REP], bf16x8 (&a)[PF][KS][A_REP],
+                                          const bf16x8* (&aptr)[A_REP], const char* base, int taps, int tap_step)
+{
+    bf16_taps<A_REP, B_REP, KS, PITCH, PF>(acc, a, aptr, base, taps, tap_step, aptr, false);
 }
 
 template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT>

@@ -84,8 +84,8 @@ mrf_stage_bf16_kernel(const MrfDev q)
     constexpr int KS  = 2;
     constexpr int PITCH = C * 2 + 16;           // bytes per column (odd multiple of 16: conflict-free 16-byte reads)
     constexpr int IMG = (WIN + 2 * VK_MRF_GUARD) * PITCH;
-    // three register copies of a four-tile window leave no room for a second tap of weight
-    // fragments in flight (the compiler would spill, and spills are HBM traffic)
+    // taps of weight fragments in flight (registers refilled in place); three register copies of a
+    // four-tile window leave room for one (with two the compiler spills, and spills are HBM traffic)
     constexpr int PF  = (SUM && NT >= 4) ? 1 : VK_PF;
 
     extern __shared__ __attribute__((aligned(16))) char lds8[];
@@ -120,15 +120,14 @@ mrf_stage_bf16_kernel(const MrfDev q)
     // most windows lie wholly inside the sequence: their workgroups skip the per-element selects
     const bool edge = (t0 - q.halo < 0) || (t0 - q.halo + WIN > L);     // workgroup-uniform
 
-    // weight fragments of the conv about to run (first tap), requested one conv ahead
+    // This wave's weight stream.  The ring `a` holds the next PF taps; the last taps of a convolution
+    // already fetch the first ones of the next (every kernel has at least PF taps: checked on the host).
     auto wfrag = [&](const void* wp, int groups) {
         return reinterpret_cast<const bf16x8*>(wp) + ((int64_t)wm * groups) * 64 + lane;
     };
-    bf16x8 a_pre[PF][KS][1];
-    {
-        const bf16x8* first[1] = {wfrag(p.w1[0][0], q.groups[0])};
-        bf16_wload<KS, 1, PF>(a_pre, first);
-    }
+    bf16x8 a[PF][KS][1];
+    const bf16x8* aptr[1] = {wfrag(p.w1[0][0], q.groups[0])};
+    bf16_wload<KS, 1, PF>(a, aptr);
 
     // accumulator-layout register r of a lane is channel 32*wm + (r & 3) + 8*(r >> 2) + 4*half;
     // four consecutive registers are four consecutive channels: one 8-byte store into an image
@@ -162,10 +161,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
 
     // one convolution of this wave's three tiles: bias, then every chunk's taps out of an image
     f32x16 acc[1][NT];
-    bf16x8 a[PF][KS][1];
-    const bf16x8* aptr[1];
-    auto conv = [&](const char* img, int conv_index, const void* wp, int groups, int taps, int dilation,
-                    const void* w_next, int groups_next) {
+    auto conv = [&](const char* img, int conv_index, int taps, int dilation, const void* w_next, int groups_next) {
         const float* bt = bias_tab + conv_index * C + wm * 32 + 4 * half;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -173,20 +169,14 @@ mrf_stage_bf16_kernel(const MrfDev q)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[0][n][r] = bv;
         }
-        aptr[0] = wfrag(wp, groups);
-#pragma unroll
-        for (int i = 0; i < PF; ++i)
-#pragma unroll
-            for (int k = 0; k < KS; ++k) a[i][k][0] = a_pre[i][k][0];
-        if (w_next != nullptr) {                                    // wave-uniform
-            const bf16x8* nx[1] = {wfrag(w_next, groups_next)};
-            bf16_wload<KS, 1, PF>(a_pre, nx);
-        }
+        const bf16x8* next[1] = {w_next != nullptr ? wfrag(w_next, groups_next) : aptr[0]};      // wave-uniform
         const int pad = ((taps - 1) >> 1) * dilation;
         const char* base = img + (VK_MRF_GUARD + col0 - pad) * PITCH + half * 16;
         if (kMrfAbl & 4) return;
         for (int chunk = 0; chunk < NCH; ++chunk)
-            bf16_taps<1, NT, KS, PITCH, PF>(acc, a, aptr, base + chunk * 64, taps, dilation * PITCH);
+            bf16_taps<1, NT, KS, PITCH, PF>(acc, a, aptr, base + chunk * 64, taps, dilation * PITCH,
+                                            next, w_next != nullptr && chunk + 1 == NCH);
+        if (w_next != nullptr) aptr[0] = next[0];
     };
 
     const __amdgpu_buffer_rsrc_t r_x = vk_rsrc(p.x + (int64_t)b * p.x_bstride, q.x_bytes);
@@ -220,7 +210,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
         for (int j = 0; j < p.n_pairs; ++j) {
             const int ci = (blk * p.n_pairs + j) * 2;
             // ---- h = conv1(lrelu(x_r)), dilated ----
-            conv(img_a, ci, p.w1[blk][j], q.groups[blk], taps, p.dilation[blk][j], p.w2[blk][j], q.groups[blk]);
+            conv(img_a, ci, taps, p.dilation[blk][j], p.w2[blk][j], q.groups[blk]);
             if (!TWO) VK_MRF_SYNC();          // every wave has read what the next lines overwrite
             put_image(img_h, acc[0], true);
             VK_MRF_SYNC();
@@ -229,7 +219,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
             const bool last_conv = last_pair && blk + 1 == p.n_blocks;
             const void* wn1 = last_conv ? nullptr : (last_pair ? p.w1[blk + 1][0] : p.w1[blk][j + 1]);
             const int gn1 = last_conv ? 0 : (last_pair ? q.groups[blk + 1] : q.groups[blk]);
-            conv(img_h, ci + 1, p.w2[blk][j], q.groups[blk], taps, 1, wn1, gn1);
+            conv(img_h, ci + 1, taps, 1, wn1, gn1);
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll

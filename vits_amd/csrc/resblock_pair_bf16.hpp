@@ -59,6 +59,12 @@ resblock_pair_bf16_kernel(const PairDev q)
         aptr[m] = reinterpret_cast<const bf16x8*>(p.w) + ((int64_t)(mt0 + m) * d.groups_per_mt) * 64 + lane;
     bf16x8 a[VK_PF][KS][A_REP];
     bf16_wload<KS, A_REP>(a, aptr);
+    // the second conv's weight stream: the first one's last taps already fetch its first ones
+    const bf16x8* w2ptr[A_REP];
+#pragma unroll
+    for (int m = 0; m < A_REP; ++m)
+        w2ptr[m] = reinterpret_cast<const bf16x8*>(q.w2) + ((int64_t)(mt0 + m) * q.groups2) * 64 + lane;
+    const bool chained = p.taps >= VK_PF;       // (a shorter kernel's ring would still hold taps of the first stream)
 
     f32x16 acc[A_REP][B_REP];
 #pragma unroll
@@ -78,14 +84,14 @@ resblock_pair_bf16_kernel(const PairDev q)
         stg.store(d, chunk, buf);
         __syncthreads();
         if (chunk + 1 < NCH) stg.issue(d, chunk + 1);
-        bf16_taps<A_REP, B_REP, KS, XP>(acc, a, aptr, buf + bcol1, p.taps, p.dilation * XP);
+        bf16_taps<A_REP, B_REP, KS, XP>(acc, a, aptr, buf + bcol1, p.taps, p.dilation * XP,
+                                        w2ptr, chained && chunk + 1 == NCH);
     }
 
-    // ---- second conv's weights and bias are requested before h is handed over ----
+    // ---- second conv's weights: in the ring already, or requested before h is handed over ----
 #pragma unroll
-    for (int m = 0; m < A_REP; ++m)
-        aptr[m] = reinterpret_cast<const bf16x8*>(q.w2) + ((int64_t)(mt0 + m) * q.groups2) * 64 + lane;
-    bf16_wload<KS, A_REP>(a, aptr);
+    for (int m = 0; m < A_REP; ++m) aptr[m] = w2ptr[m];
+    if (!chained) bf16_wload<KS, A_REP>(a, aptr);
 
     __syncthreads();                    // every wave is done reading the x tile
     {
