@@ -564,6 +564,9 @@ def test_fused_mrf_stage_rejects_bad_arguments():
         native.mrf_stage(x, torch.empty_like(x), [(11, [(w, b, w, b, d) for d in (1, 3, 7)])], slope=0.1)
     with pytest.raises(native.NativeError):          # out on top of x
         native.mrf_stage(x, x, [(11, [(w, b, w, b, 1)])], slope=0.1)
+    w1 = packing.pack_conv_weight_bf16(_rand(32, 32, 1, seed=3), mi.ck_bf16, mi.rows_per_block).to(DEV)
+    with pytest.raises(native.NativeError):          # a one-tap kernel (the weight stream needs at least three)
+        native.mrf_stage(x, torch.empty_like(x), [(1, [(w1, b, w1, b, 1)])], slope=0.1)
     m8 = native.mrf_info(128, native.PREC_BF16)
     w8 = packing.pack_conv_weight_bf16(_rand(128, 128, 3, seed=2), m8.ck_bf16, m8.rows_per_block).to(DEV)
     b8 = torch.zeros(128, device=DEV)

@@ -74,7 +74,7 @@ class ResBlockPlan:
         # narrower stages run whole through it.
         self.chain = None
         mi = native.mrf_info(rb.channels, prec) if prec == native.PREC_BF16 else None
-        reach = sum((k - 1) // 2 * (d + 1) for d in rb.dilation) if k % 2 == 1 else 1 << 30
+        reach = sum((k - 1) // 2 * (d + 1) for d in rb.dilation) if (k % 2 == 1 and k >= 3) else 1 << 30
         if (self.fused and mi is not None and os.environ.get("VITS_AMD_MRF_FUSION", "1") != "0"
                 and reach <= self.chain_max_reach and len(rb.dilation) <= native.MRF_MAX_PAIRS
                 and all((k - 1) // 2 * d <= 32 for d in rb.dilation)):
@@ -197,7 +197,7 @@ class DecoderPlan:
             return None
         for rb in rbs:
             k = rb.kernel_size
-            if k % 2 == 0 or sum((k - 1) // 2 * (d + 1) for d in rb.dilation) > 64 \
+            if k % 2 == 0 or k < 3 or sum((k - 1) // 2 * (d + 1) for d in rb.dilation) > 64 \
                     or any((k - 1) // 2 * d > 32 for d in rb.dilation):
                 return None
         blocks = []
