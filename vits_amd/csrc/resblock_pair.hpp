@@ -24,7 +24,8 @@ struct PairDev {
 constexpr int VK_PAIR_OVERLAP = 12;
 
 // out = acc + x (+ running sum) for the first TNO columns of the workgroup's window.
-template <int B_REP, int EPI, int TNO>
+// RES_IN_ACC: the accumulators were started at bias + x, so x is not read again here.
+template <int B_REP, int EPI, int TNO, bool RES_IN_ACC = false>
 __device__ __forceinline__ void pair_epilogue(const ConvDev& d, f32x16 (&acc)[B_REP], int b, int t0, int wm, int wn,
                                               int half, int l31)
 {
@@ -54,7 +55,7 @@ __device__ __forceinline__ void pair_epilogue(const ConvDev& d, f32x16 (&acc)[B_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = R0 + (r & 3) + 8 * (r >> 2);
-            rv[r] = vk_bld(r_res, vr + 128 * n, rr * (int)p.res_cstride * 4);
+            rv[r] = RES_IN_ACC ? 0.0f : vk_bld(r_res, vr + 128 * n, rr * (int)p.res_cstride * 4);
             sv[r] = 0.0f;
             if constexpr (NEED_ACC) sv[r] = vk_bld(r_out2, vo2 + 128 * n, rr * (int)p.out2_cstride * 4);
         }
@@ -62,11 +63,11 @@ __device__ __forceinline__ void pair_epilogue(const ConvDev& d, f32x16 (&acc)[B_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = R0 + (r & 3) + 8 * (r >> 2);
-                const float v = acc[n][r];
+                const float v = RES_IN_ACC ? acc[n][r] : acc[n][r] + rv[r];
                 const int so = rr * (int)p.out_cstride * 4;
-                if constexpr (EPI == VK_EPI_RESID)          vk_bst(v + rv[r], r_out, vo + 128 * n, so);
-                else if constexpr (EPI == VK_EPI_RESID_ACC) vk_bst(sv[r] + (v + rv[r]), r_out, vo + 128 * n, so);
-                else                                        vk_bst((sv[r] + (v + rv[r])) / p.navg, r_out, vo + 128 * n, so);
+                if constexpr (EPI == VK_EPI_RESID)          vk_bst(v, r_out, vo + 128 * n, so);
+                else if constexpr (EPI == VK_EPI_RESID_ACC) vk_bst(sv[r] + v, r_out, vo + 128 * n, so);
+                else                                        vk_bst((sv[r] + v) / p.navg, r_out, vo + 128 * n, so);
             }
         }
     }

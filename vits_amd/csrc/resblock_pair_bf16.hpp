@@ -6,8 +6,8 @@
 // The x window is staged channel-minor in bf16 exactly as in conv_bf16_kernel; h is activated,
 // rounded and written channel-minor into the same LDS space (zero outside [0, L)), from where
 // the second convolution takes its B fragments.  In bf16 the whole-channel h tile of a 256
-// column window fits LDS up to 128 channels.  The results are identical to running the two
-// convolutions as separate conv_bf16_kernel launches (same roundings, same summation order).
+// column window fits LDS up to 256 channels.  The same roundings as two separate conv_bf16_kernel
+// launches; the residual enters the sum first instead of last (bias + x + products).
 #pragma once
 #include "conv_bf16.hpp"
 #include "resblock_pair.hpp"
@@ -121,15 +121,25 @@ resblock_pair_bf16_kernel(const PairDev q)
                 }
         }
     }
+    // The second conv's accumulators start at bias + x, the residual: its loads are in flight while
+    // the workgroup meets at the barrier below, and the epilogue is left with stores only (read
+    // there, x stood between the last matrix instruction and the first store of every workgroup).
+    {
+        const __amdgpu_buffer_rsrc_t r_res = vk_rsrc(p.res + (int64_t)b * p.res_bstride, d.res_bytes);
+        const int vr = 4 * (4 * half * (int)p.res_cstride + t0 + wn * TNW + l31);
 #pragma unroll
-    for (int m = 0; m < A_REP; ++m) {
-        float bv2[16];
+        for (int m = 0; m < A_REP; ++m) {
+            float bv2[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv2[r] = q.bias2 ? q.bias2[(mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] : 0.0f;
+            for (int r = 0; r < 16; ++r) bv2[r] = q.bias2 ? q.bias2[(mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] : 0.0f;
 #pragma unroll
-        for (int n = 0; n < B_REP; ++n)
+            for (int n = 0; n < B_REP; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = bv2[r];
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2);
+                    acc[m][n][r] = bv2[r] + vk_bld(r_res, vr + 128 * n, rr * (int)p.res_cstride * 4);
+                }
+        }
     }
     __syncthreads();
 
@@ -139,7 +149,7 @@ resblock_pair_bf16_kernel(const PairDev q)
         bf16_taps<A_REP, B_REP, KS, HP>(acc, a, aptr, lds8 + bcol2 + chunk * (CK * 2), p.taps, HP);
 
 #pragma unroll
-    for (int m = 0; m < A_REP; ++m) pair_epilogue<B_REP, EPI, TNO>(d, acc[m], b, t0, mt0 + m, wn, half, l31);
+    for (int m = 0; m < A_REP; ++m) pair_epilogue<B_REP, EPI, TNO, true>(d, acc[m], b, t0, mt0 + m, wn, half, l31);
 }
 
 struct PairGeomBf16 { int a_rep, b_rep, wm, wn; };
