@@ -160,27 +160,29 @@ mrf_stage_bf16_kernel(const MrfDev q)
     };
 
     // one convolution of this wave's three tiles: bias, then every chunk's taps out of an image
+    // `onto`: the products are added to what `dst` holds (plus the bias) instead of starting at the bias
     f32x16 acc[1][NT];
-    auto conv = [&](const char* img, int conv_index, int taps, int dilation, const void* w_next, int groups_next) {
+    auto conv = [&](f32x16 (&dst)[1][NT], bool onto, const char* img, int conv_index, int taps, int dilation,
+                    const void* w_next, int groups_next) {
         const float* bt = bias_tab + conv_index * C + wm * 32 + 4 * half;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = bt[(r & 3) + 8 * (r >> 2)];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[0][n][r] = bv;
+            for (int n = 0; n < NT; ++n) dst[0][n][r] = onto ? dst[0][n][r] + bv : bv;
         }
         const bf16x8* next[1] = {w_next != nullptr ? wfrag(w_next, groups_next) : aptr[0]};      // wave-uniform
         const int pad = ((taps - 1) >> 1) * dilation;
         const char* base = img + (VK_MRF_GUARD + col0 - pad) * PITCH + half * 16;
         if (kMrfAbl & 4) return;
         for (int chunk = 0; chunk < NCH; ++chunk)
-            bf16_taps<1, NT, KS, PITCH, PF>(acc, a, aptr, base + chunk * 64, taps, dilation * PITCH,
+            bf16_taps<1, NT, KS, PITCH, PF>(dst, a, aptr, base + chunk * 64, taps, dilation * PITCH,
                                             next, w_next != nullptr && chunk + 1 == NCH);
         if (w_next != nullptr) aptr[0] = next[0];
     };
 
     const __amdgpu_buffer_rsrc_t r_x = vk_rsrc(p.x + (int64_t)b * p.x_bstride, q.x_bytes);
-    f32x16 xr[NT], tot[SUM ? NT : 1];
+    f32x16 xr[1][NT], tot[SUM ? NT : 1];
     if (SUM) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -200,39 +202,35 @@ mrf_stage_bf16_kernel(const MrfDev q)
                 const int row = wm * 32 + (r & 3) + 8 * (r >> 2);                  // wave-uniform part
                 const int voff = 4 * (tc + 4 * half * (int)p.x_cstride);
                 const float v = vk_bld(r_x, voff, row * (int)p.x_cstride * 4);
-                xr[n][r] = inside[n] ? v : 0.0f;
+                xr[0][n][r] = inside[n] ? v : 0.0f;
             }
         }
-        put_image(img_a, xr, false);
+        put_image(img_a, xr[0], false);
         VK_MRF_SYNC();
 
         const int taps = p.taps[blk];
         for (int j = 0; j < p.n_pairs; ++j) {
             const int ci = (blk * p.n_pairs + j) * 2;
             // ---- h = conv1(lrelu(x_r)), dilated ----
-            conv(img_a, ci, taps, p.dilation[blk][j], p.w2[blk][j], q.groups[blk]);
+            conv(acc, false, img_a, ci, taps, p.dilation[blk][j], p.w2[blk][j], q.groups[blk]);
             if (!TWO) VK_MRF_SYNC();          // every wave has read what the next lines overwrite
             put_image(img_h, acc[0], true);
             VK_MRF_SYNC();
-            // ---- x_r = conv2(lrelu(h)) + x_r ----
+            // ---- x_r = conv2(lrelu(h)) + x_r: the matrix instructions accumulate onto x_r + bias ----
             const bool last_pair = j + 1 == p.n_pairs;
             const bool last_conv = last_pair && blk + 1 == p.n_blocks;
             const void* wn1 = last_conv ? nullptr : (last_pair ? p.w1[blk + 1][0] : p.w1[blk][j + 1]);
             const int gn1 = last_conv ? 0 : (last_pair ? q.groups[blk + 1] : q.groups[blk]);
-            conv(img_h, ci + 1, taps, 1, wn1, gn1);
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xr[n][r] = acc[0][n][r] + xr[n][r];
+            conv(xr, true, img_h, ci + 1, taps, 1, wn1, gn1);     // accumulated straight onto the residual stream
             if (edge) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xr[n][r] = inside[n] ? xr[n][r] : 0.0f;
+                    for (int r = 0; r < 16; ++r) xr[0][n][r] = inside[n] ? xr[0][n][r] : 0.0f;
             }
             if (!last_pair) {
                 if (!TWO) VK_MRF_SYNC();
-                put_image(img_a, xr, false);
+                put_image(img_a, xr[0], false);
                 VK_MRF_SYNC();
             }
         }
@@ -240,7 +238,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tot[n][r] += xr[n][r];
+                for (int r = 0; r < 16; ++r) tot[n][r] += xr[0][n][r];
         }
         if (!TWO && blk + 1 < p.n_blocks) VK_MRF_SYNC();     // the next resblock's input replaces h
     }
@@ -256,7 +254,7 @@ mrf_stage_bf16_kernel(const MrfDev q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + (r & 3) + 8 * (r >> 2);
-                const float v = SUM ? tot[n][r] / nb : xr[n][r];
+                const float v = SUM ? tot[n][r] / nb : xr[0][n][r];
                 vk_bst(v, r_out, 4 * (t + 4 * half * (int)p.out_cstride), row * (int)p.out_cstride * 4);
             }
         }
