@@ -21,6 +21,8 @@ class GraphedCall:
             for _ in range(warmup):
                 fn(*self._static_in)
         torch.cuda.current_stream(self._static_in[0].device).wait_stream(stream)
+        from . import native
+        native.ensure_capture_workspace(self._static_in[0].device)      # scratch of split channel loops, made outside the capture
         self._graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self._graph):
             self._static_out = fn(*self._static_in)

@@ -263,14 +263,33 @@ _workspaces = {}
 def workspace(device):
     """Scratch for split channel loops, one per (device, stream): launches on different streams
     may overlap in time and must not share arrival counters.  Zeroed once; every launch leaves the
-    counters zero."""
+    counters zero.  A stream that is being captured into a graph takes the device's capture
+    workspace (made ahead of the capture by ``ensure_capture_workspace``): capture streams come
+    and go, and a workspace made during capture would live in the graph's private pool."""
     device = torch.device(device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            ws = _workspaces.get((device.index, "capture"))
+            if ws is None:
+                raise NativeError("no capture workspace: call native.ensure_capture_workspace(device) before the capture")
+            return ws
         ws = torch.zeros(WS_BYTES // 4, dtype=torch.float32, device=device)
         _workspaces[key] = ws
     return ws
+
+
+def ensure_capture_workspace(device):
+    """Make the workspace that launches on a capturing stream use (see ``workspace``).  Call it
+    outside any capture; graphs captured on one device share it, so they must not replay
+    concurrently with each other."""
+    device = torch.device(device)
+    key = (device.index, "capture")
+    if key not in _workspaces:
+        _workspaces[key] = torch.zeros(WS_BYTES // 4, dtype=torch.float32, device=device)
+        torch.cuda.synchronize(device)
+    return _workspaces[key]
 
 
 def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue,
