@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 6
+#define VK_ABI_VERSION 7
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -135,8 +135,8 @@ typedef struct {
 int         vk_abi_version(void);
 const char* vk_last_error(void);
 /* sizeof of a struct as the library was compiled, so that a binding can check its own mirror:
- * which = 0 vk_conv_args, 1 vk_pair_args, 2 vk_wn_args, 3 vk_tile_info, 4 vk_mrf_args; 0 for an
- * unknown id. */
+ * which = 0 vk_conv_args, 1 vk_pair_args, 2 vk_wn_args, 3 vk_tile_info, 4 vk_mrf_args,
+ * 5 vk_dds_args; 0 for an unknown id. */
 size_t      vk_sizeof_args(int which);
 int         vk_tile_query(int tile, vk_tile_info* info);
 
@@ -249,6 +249,57 @@ typedef struct {
 
 int vk_mrf_query(int channels, int precision, vk_tile_info* info);
 int vk_mrf_stage(const vk_mrf_args* a, void* stream);
+
+/* ---- token-level blocks of the stochastic duration predictor (reverse direction) -----
+ * A dilated depth-separable stack (stochastic_duration_predictor.py:285-323 `DDSConv`): per
+ * layer i a depthwise `taps`-tap conv of x * mask with dilation taps**i, LayerNorm over
+ * channels, GELU, 1x1 conv, LayerNorm, GELU, added onto x; at the end x * mask.  One launch
+ * per layer; a workgroup owns VK_DDS_COLUMNS token columns of all VK_DDS_CHANNELS channels, so
+ * a sentence of a few dozen tokens still spreads over several CUs, and everything between the
+ * layer's input and output stays in registers and LDS.  The 1x1 convs before and after the
+ * stack, and for a coupling flow the spline, ride in the first and last layer's launch.
+ * fp32 on the vector ALUs.
+ *
+ *   vk_dds_condition  out = proj( DDSConv( pre(x) + add_vec ) ) * mask
+ *                     (stochastic_duration_predictor.py:397-402: `pre`, `cond`, `convs`, `proj`)
+ *   vk_dds_coupling   one ConvFlow in reverse (stochastic_duration_predictor.py:230-274) with the
+ *                     Flip before it folded into `pass_channel`: x0 = in_scale * x[:, pass_channel],
+ *                     h = proj( DDSConv( pre(x0) + add_map ) ) * mask, the other channel goes
+ *                     through the inverse rational-quadratic spline with parameters h (:122-201),
+ *                     both channels are written to `out` times mask; with `affine_m` the reversed
+ *                     ElementwiseAffine (:213-228) is applied to the result as well.
+ *
+ * 1x1 weights are passed input-major (w_t[i * rows + o] = weight[o, i]) so that the lanes of
+ * a wavefront read consecutive output rows.  `layers` holds, per layer and in this order:
+ * depthwise weight [C, taps], depthwise bias [C], first LayerNorm gamma [C], beta [C], 1x1
+ * weight [C, C] input-major, 1x1 bias [C], second LayerNorm gamma [C], beta [C].
+ * `workspace` holds the stream between the layers' launches: vk_dds_workspace_bytes(batch,
+ * length) bytes, contents irrelevant before and after the call.  `out` must not overlap `x`. */
+#define VK_DDS_CHANNELS 192
+#define VK_DDS_COLUMNS  8
+typedef struct {
+    const float* x;        int64_t x_bstride;   int64_t x_cstride;   /* condition: [B, C, T]; coupling: z [B, 2, T] */
+    const float* pre_wt;   /* condition: [C, C] input-major; coupling: [C] (weight of the 1 -> C conv) */
+    const float* pre_b;    /* [C] */
+    const float* add_vec;  /* condition: [B, C] added after `pre` (speaker conditioning) or NULL */
+    const float* add_map;  int64_t add_map_bstride;                  /* coupling: [B, C, T] added after `pre` */
+    const float* layers;
+    const float* proj_wt;  /* condition: [C, C] input-major; coupling: [C, 3 * num_bins - 1] input-major */
+    const float* proj_b;
+    const float* mask;     /* [B, T] 0/1 floats */
+    float* out;            int64_t out_bstride; int64_t out_cstride; /* condition: [B, C, T]; coupling: [B, 2, T] */
+    const float* affine_m; const float* affine_logs;                 /* coupling: [2] each, or both NULL */
+    void*   workspace;     int64_t workspace_bytes;
+    int32_t batch, length, n_layers, taps;                           /* taps 3, up to 3 layers */
+    int32_t pass_channel;  /* coupling: channel of x that conditions (0 or 1); the other one is transformed */
+    int32_t num_bins;      /* coupling: 10 */
+    float   tail_bound;    /* coupling: identity outside [-tail_bound, tail_bound] */
+    float   in_scale;      /* coupling: x is read as in_scale * x (noise scale of the first flow) */
+} vk_dds_args;
+
+int64_t vk_dds_workspace_bytes(int batch, int length);
+int vk_dds_condition(const vk_dds_args* a, void* stream);
+int vk_dds_coupling(const vk_dds_args* a, void* stream);
 
 /* out[b, o] = bias[o] + sum_i W[o, i] * g[b, i]   (speaker-conditioning 1x1 convs on
  * [B, G, 1] inputs: decoder.py:91,112 `cond`; wn.py:41-42,66 `condition_layer`).

@@ -43,6 +43,7 @@ extern "C" size_t vk_sizeof_args(int which)
     case 2: return sizeof(vk_wn_args);
     case 3: return sizeof(vk_tile_info);
     case 4: return sizeof(vk_mrf_args);
+    case 5: return sizeof(vk_dds_args);
     default: return 0;
     }
 }

@@ -1,7 +1,10 @@
-"""Stochastic duration predictor, inference (reverse) direction: stock PyTorch.
+"""Stochastic duration predictor, inference (reverse) direction.
 
 Upstream of the hot path; kept so that ``VitsGenerator`` loads a complete ``netG_cpu.pth``
-and ``text_to_speech`` runs end to end.  Same constructor arguments and ``state_dict`` keys
+and ``text_to_speech`` runs end to end.  On the GPU the reverse pass is five launches of the
+token kernels (csrc/token_kernels.hip: the conditioning stack, then one launch per coupling
+flow with its spline); on CPU tensors, or with ``use_token_kernels = False``, it is the
+layer-by-layer stock PyTorch form below.  Same constructor arguments and ``state_dict`` keys
 as /root/reference/module/model_component/stochastic_duration_predictor.py
 (``StochasticDurationPredictor`` :325-415, ``ConvFlow`` :230-274, ``DDSConv`` :285-323,
 ``ElementwiseAffine`` :213-228, ``Flip`` :276-283, ``Log`` :203-211, splines :20-201);
@@ -15,10 +18,14 @@ so the GPU path has no data-dependent shapes or host synchronisation.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ... import native
+from ...engine import PlanCache
 
 MIN_BIN_WIDTH = 1e-3
 MIN_BIN_HEIGHT = 1e-3
@@ -142,7 +149,64 @@ class ConvFlow(nn.Module):
         return torch.cat([x0, x1], 1) * x_mask
 
 
+def _f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _pack_dds(dds: DDSConv, device) -> torch.Tensor:
+    """A DDSConv's parameters in the order the token kernels read them (1x1 weights input-major)."""
+    parts = []
+    for sep, pw, n1, n2 in zip(dds.convs_sep, dds.convs_1x1, dds.norms_1, dds.norms_2):
+        parts += [sep.weight.reshape(-1), sep.bias, n1.weight, n1.bias,
+                  pw.weight[:, :, 0].t().reshape(-1), pw.bias, n2.weight, n2.bias]
+    return _f32(torch.cat([p.detach().reshape(-1).float() for p in parts]), device)
+
+
+class SdpPlan:
+    """The reverse pass's weights on one device, laid out for the token kernels, and its launch list."""
+
+    def __init__(self, sdp: "StochasticDurationPredictor", device):
+        self.cond_w = _f32(sdp.cond.weight[:, :, 0], device)
+        self.cond_b = _f32(sdp.cond.bias, device)
+        self.pre_wt = _f32(sdp.pre.weight[:, :, 0].t(), device)
+        self.pre_b = _f32(sdp.pre.bias, device)
+        self.proj_wt = _f32(sdp.proj.weight[:, :, 0].t(), device)
+        self.proj_b = _f32(sdp.proj.bias, device)
+        self.layers = _pack_dds(sdp.convs, device)
+        self.n_layers = sdp.convs.n_layers
+        self.taps = sdp.convs.convs_sep[0].kernel_size[0]
+        # The reversed module list with the Flips folded away: a Flip only renames the two
+        # channels, so each coupling launch is told which stored channel conditions.
+        order = list(reversed(sdp.flows))
+        order = order[:-2] + [order[-1]]
+        flipped = 0
+        self.couplings = []
+        self.affine = None
+        for flow in order:
+            if isinstance(flow, Flip):
+                flipped ^= 1
+            elif isinstance(flow, ConvFlow):
+                if self.affine is not None:
+                    raise NotImplementedError("a coupling flow after the elementwise affine")
+                self.couplings.append(dict(
+                    pre_w=_f32(flow.pre.weight.reshape(-1), device), pre_b=_f32(flow.pre.bias, device),
+                    layers=_pack_dds(flow.convs, device), n_layers=flow.convs.n_layers,
+                    taps=flow.convs.convs_sep[0].kernel_size[0],
+                    proj_wt=_f32(flow.proj.weight[:, :, 0].t(), device), proj_b=_f32(flow.proj.bias, device),
+                    pass_channel=flipped, num_bins=flow.num_bins, tail_bound=flow.tail_bound))
+            elif isinstance(flow, ElementwiseAffine):
+                idx = [flipped, 1 - flipped]                   # stored channel c holds logical channel c ^ flipped
+                inv = [idx.index(0), idx.index(1)]
+                self.affine = (_f32(flow.m.reshape(-1)[inv], device), _f32(flow.logs.reshape(-1)[inv], device))
+            else:
+                raise NotImplementedError(type(flow).__name__)
+        self.out_channel = flipped                              # stored channel that holds logical channel 0
+
+
 class StochasticDurationPredictor(nn.Module):
+    # VITS_AMD_TOKEN_KERNELS=0 (or the attribute on an instance) keeps the GPU pass in stock PyTorch
+    use_token_kernels = os.environ.get("VITS_AMD_TOKEN_KERNELS", "1") != "0"
+
     def __init__(self, speaker_id_embedding_dim, phoneme_embedding_dim=192, filter_channels=192,
                  kernel_size=3, p_dropout=0.5, n_flows=4):
         super().__init__()
@@ -164,6 +228,33 @@ class StochasticDurationPredictor(nn.Module):
         self.proj = nn.Conv1d(filter_channels, filter_channels, 1)
         self.convs = DDSConv(filter_channels, kernel_size, n_layers=3, p_dropout=p_dropout)
         self.cond = nn.Conv1d(speaker_id_embedding_dim, filter_channels, 1)
+        self._plans = PlanCache(self, lambda dev: SdpPlan(self, dev))
+
+    def _reverse_on_token_kernels(self, text_encoded, text_mask, speaker_id_embedded, noise_scale, noise):
+        plan = self._plans.get(text_encoded.device)
+        B, H, T = text_encoded.shape
+        dev = text_encoded.device
+        x = text_encoded.to(torch.float32).contiguous()
+        mask2 = text_mask.to(torch.float32).expand(B, 1, T).reshape(B, T).contiguous()
+        add_vec = None
+        if speaker_id_embedded is not None:
+            add_vec = torch.empty(B, H, device=dev, dtype=torch.float32)
+            native.speaker_linear(speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous(),
+                                  plan.cond_w, plan.cond_b, add_vec)
+        g = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+        native.dds_condition(x, plan.pre_wt, plan.pre_b, add_vec, plan.layers, plan.n_layers, plan.taps,
+                             plan.proj_wt, plan.proj_b, mask2, g)
+        z = noise.to(device=dev, dtype=torch.float32).contiguous()
+        bufs = [torch.empty_like(z), torch.empty_like(z)]
+        for i, c in enumerate(plan.couplings):
+            last = i == len(plan.couplings) - 1
+            native.dds_coupling(z, c["pre_w"], c["pre_b"], g, c["layers"], c["n_layers"], c["taps"], c["proj_wt"],
+                                c["proj_b"], mask2, bufs[i & 1], pass_channel=c["pass_channel"],
+                                num_bins=c["num_bins"], tail_bound=c["tail_bound"],
+                                in_scale=float(noise_scale) if i == 0 else 1.0,
+                                affine=plan.affine if last else None)
+            z = bufs[i & 1]
+        return z[:, plan.out_channel:plan.out_channel + 1]
 
     @torch.no_grad()
     def forward(self, text_encoded, text_mask, duration_of_each_phoneme=None, speaker_id_embedded=None,
@@ -172,6 +263,11 @@ class StochasticDurationPredictor(nn.Module):
         standard normal) replaces the internal ``torch.randn`` draw."""
         if not reverse:
             raise NotImplementedError("the training direction of the duration predictor is out of scope")
+        if text_encoded.is_cuda and self.use_token_kernels and len(self.flows) > 3:
+            if noise is None:
+                noise = torch.randn(text_encoded.size(0), 2, text_encoded.size(2)).to(
+                    device=text_encoded.device, dtype=text_encoded.dtype)
+            return self._reverse_on_token_kernels(text_encoded, text_mask, speaker_id_embedded, noise_scale, noise)
         x = self.pre(text_encoded)
         if speaker_id_embedded is not None:
             x = x + self.cond(speaker_id_embedded)

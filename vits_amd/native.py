@@ -106,6 +106,28 @@ class MrfArgs(C.Structure):
     ]
 
 
+class DdsArgs(C.Structure):
+    """Mirror of ``vk_dds_args``."""
+    _fields_ = [
+        ("x", _fp), ("x_bstride", C.c_int64), ("x_cstride", C.c_int64),
+        ("pre_wt", _fp), ("pre_b", _fp),
+        ("add_vec", _fp),
+        ("add_map", _fp), ("add_map_bstride", C.c_int64),
+        ("layers", _fp),
+        ("proj_wt", _fp), ("proj_b", _fp),
+        ("mask", _fp),
+        ("out", _fp), ("out_bstride", C.c_int64), ("out_cstride", C.c_int64),
+        ("affine_m", _fp), ("affine_logs", _fp),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("batch", C.c_int32), ("length", C.c_int32), ("n_layers", C.c_int32), ("taps", C.c_int32),
+        ("pass_channel", C.c_int32), ("num_bins", C.c_int32),
+        ("tail_bound", C.c_float), ("in_scale", C.c_float),
+    ]
+
+
+DDS_CHANNELS = 192
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -149,13 +171,17 @@ def lib():
         L.vk_conv1d_static.argtypes = [C.POINTER(ConvArgs), C.c_void_p]
         L.vk_conv1d_workspace_bytes.argtypes = [C.POINTER(ConvArgs)]
         L.vk_conv1d_workspace_bytes.restype = C.c_int64
+        L.vk_dds_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        L.vk_dds_workspace_bytes.restype = C.c_int64
+        L.vk_dds_condition.argtypes = [C.POINTER(DdsArgs), C.c_void_p]
+        L.vk_dds_coupling.argtypes = [C.POINTER(DdsArgs), C.c_void_p]
         L.vk_sizeof_args.argtypes = [C.c_int]
         L.vk_sizeof_args.restype = C.c_size_t
         want = header_abi_version()
         if L.vk_abi_version() != want:
             raise NativeError(f"{_lib_path}: ABI version {L.vk_abi_version()}, include/vits_amd.h declares {want}; "
                               "rebuild with `python -m vits_amd.build`")
-        for which, mirror in enumerate((ConvArgs, PairArgs, WnArgs, TileInfo, MrfArgs)):
+        for which, mirror in enumerate((ConvArgs, PairArgs, WnArgs, TileInfo, MrfArgs, DdsArgs)):
             if L.vk_sizeof_args(which) != C.sizeof(mirror):
                 raise NativeError(f"{mirror.__name__} is {C.sizeof(mirror)} bytes here, "
                                   f"{L.vk_sizeof_args(which)} in the library: native.py is out of step with the header")
@@ -456,6 +482,55 @@ def wn_layer(x, w_in, cond, cond_bstride, w_rs, bias_rs, x_out, skip, mask, *, t
     L, sp = lib(), stream_ptr(x.device)
     check(_timed(f"wn_layer[{'last' if last else 'mid'}]", flops, nbytes, x.device,
                  lambda: L.vk_wn_layer(C.byref(a), sp), f"B{B} L{T} h{H} k{taps} d{dilation}"), "vk_wn_layer")
+
+
+def _dds_common(a, x, pre_wt, pre_b, layers, n_layers, taps, proj_wt, proj_b, mask, out):
+    assert x.is_cuda and mask.dtype == torch.float32 and mask.is_contiguous() and mask.dim() == 2
+    a.x, a.x_bstride, a.x_cstride = _view(x)
+    a.pre_wt, a.pre_b = pre_wt.data_ptr(), pre_b.data_ptr()
+    a.layers, a.n_layers, a.taps = layers.data_ptr(), n_layers, taps
+    a.proj_wt, a.proj_b = proj_wt.data_ptr(), proj_b.data_ptr()
+    a.mask = mask.data_ptr()
+    a.out, a.out_bstride, a.out_cstride = _view(out)
+    a.batch, a.length = x.shape[0], x.shape[2]
+    if n_layers > 1:                      # the stream between the layers' launches
+        need = lib().vk_dds_workspace_bytes(a.batch, a.length)
+        ws = torch.empty(need // 4, device=x.device, dtype=torch.float32)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+        return ws
+    return None
+
+
+def dds_condition(x, pre_wt, pre_b, add_vec, layers, n_layers, taps, proj_wt, proj_b, mask, out):
+    """out = proj(DDSConv(pre(x) + add_vec)) * mask, one launch per layer: x, out [B, 192, T]; 1x1 weights
+    input-major; ``layers`` packed as the header describes; add_vec [B, 192] or None."""
+    a = DdsArgs()
+    ws = _dds_common(a, x, pre_wt, pre_b, layers, n_layers, taps, proj_wt, proj_b, mask, out)  # noqa: F841 (kept alive)
+    a.add_vec = add_vec.data_ptr() if add_vec is not None else None
+    B, H, T = x.shape
+    flops = 2.0 * B * T * H * H * (n_layers + 2)
+    L, sp = lib(), stream_ptr(x.device)
+    check(_timed("dds_condition", flops, 8.0 * B * H * T, x.device,
+                 lambda: L.vk_dds_condition(C.byref(a), sp), f"B{B} T{T}"), "vk_dds_condition")
+
+
+def dds_coupling(z, pre_w, pre_b, g, layers, n_layers, taps, proj_wt, proj_b, mask, out, *, pass_channel,
+                 num_bins, tail_bound, in_scale=1.0, affine=None):
+    """One reversed ConvFlow: out[:, pass] = z[:, pass], out[:, other] = inverse spline of z[:, other]
+    with parameters proj(DDSConv(pre(z[:, pass]) + g)), both times mask; ``affine`` = (m, logs) of a
+    reversed ElementwiseAffine applied to the result.  z, out [B, 2, T] (distinct), g [B, 192, T]."""
+    assert g.is_contiguous() and g.dtype == torch.float32
+    a = DdsArgs()
+    ws = _dds_common(a, z, pre_w, pre_b, layers, n_layers, taps, proj_wt, proj_b, mask, out)  # noqa: F841 (kept alive)
+    a.add_map, a.add_map_bstride = g.data_ptr(), g.stride(0)
+    a.pass_channel, a.num_bins, a.tail_bound, a.in_scale = pass_channel, num_bins, tail_bound, in_scale
+    if affine is not None:
+        a.affine_m, a.affine_logs = affine[0].data_ptr(), affine[1].data_ptr()
+    B, _, T = z.shape
+    flops = 2.0 * B * T * DDS_CHANNELS * DDS_CHANNELS * n_layers
+    L, sp = lib(), stream_ptr(z.device)
+    check(_timed("dds_coupling", flops, 4.0 * B * DDS_CHANNELS * T, z.device,
+                 lambda: L.vk_dds_coupling(C.byref(a), sp), f"B{B} T{T}"), "vk_dds_coupling")
 
 
 def speaker_linear(g, w, bias, out):
