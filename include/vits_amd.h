@@ -301,6 +301,39 @@ int64_t vk_dds_workspace_bytes(int batch, int length);
 int vk_dds_condition(const vk_dds_args* a, void* stream);
 int vk_dds_coupling(const vk_dds_args* a, void* stream);
 
+/* ---- token-level blocks of the text encoder ------------------------------------------
+ * The encoder's 1x1 and 3-tap convolutions go through vk_conv1d; these two are what is left
+ * between them.  Tensors are dense [B, C, T] fp32.
+ *
+ * vk_channel_norm: out = LayerNorm over the channel axis (eps 1e-5, gamma / beta [C]) times
+ * mask [B, T] (NULL: no mask): `norm_layers_1/2` at text_encoder.py:233-243 (the reference
+ * transposes to [B, T, C] around nn.LayerNorm).  C = 192.
+ *
+ * vk_rel_attention: multi-head attention with learned relative-position keys and values inside
+ * a window (text_encoder.py:58-99, 101-174): qkv [B, 3 * heads * head_dim, T] holds the
+ * projected queries, keys and values (rows h * head_dim .. of each third belong to head h),
+ * scores = q k^T / sqrt(head_dim) + q . emb_k[j - i + window] for |j - i| <= window, positions
+ * with mask_i * mask_j == 0 set to -1e4, softmax over keys, out = p v + sum_r p[i, i + r -
+ * window] emb_v[r]; out [B, heads * head_dim, T].  emb_k, emb_v are [2 * window + 1, head_dim].
+ * head_dim = 96, window = 4, T <= VK_ATT_MAX_LENGTH.                                      */
+#define VK_ATT_HEAD_DIM   96
+#define VK_ATT_WINDOW     4
+#define VK_ATT_MAX_LENGTH 1024
+int vk_channel_norm(const float* x, const float* gamma, const float* beta, const float* mask, float* out,
+                    int batch, int channels, int length, void* stream);
+int vk_rel_attention(const float* qkv, const float* emb_k, const float* emb_v, const float* mask, float* out,
+                     int batch, int heads, int head_dim, int window, int length, void* stream);
+
+/* Token level -> frame level (vits_generator.py:45-64 `generate_path`, :177-182): frame y of item
+ * b takes the statistics of the token x with cum[x - 1] <= y < cum[x], cum the running sum of
+ * durations[b, :] (whole numbers, zero for padded tokens); frames at or beyond the total are
+ * zero.  m, logs [B, C, tokens] -> m_out, logs_out [B, C, frames] (dense); frame_mask [B, frames]
+ * = 1 for y < max(total, 1).  The reference builds the 0/1 alignment matrix and multiplies by
+ * it; the gather gives the same values.  tokens <= VK_EXPAND_MAX_TOKENS.                  */
+#define VK_EXPAND_MAX_TOKENS 2048
+int vk_expand_prior(const float* durations, const float* m, const float* logs, float* m_out, float* logs_out,
+                    float* frame_mask, int batch, int channels, int tokens, int frames, void* stream);
+
 /* out[b, o] = bias[o] + sum_i W[o, i] * g[b, i]   (speaker-conditioning 1x1 convs on
  * [B, G, 1] inputs: decoder.py:91,112 `cond`; wn.py:41-42,66 `condition_layer`).
  * W is [n_out, n_in] row-major (weight norm already folded). One wavefront per output. */

@@ -98,3 +98,101 @@ def test_dds_rejects_bad_arguments(gens):
     with pytest.raises(native.NativeError, match="pass_channel"):
         native.dds_coupling(z, c["pre_w"], c["pre_b"], g, c["layers"], 3, 3, c["proj_wt"], c["proj_b"], mask, out,
                             pass_channel=2, num_bins=10, tail_bound=5.0)
+
+
+@pytest.mark.parametrize("B,T,lens", [(1, 43, [43]), (3, 87, [87, 60, 1]), (2, 200, [200, 131]), (1, 1, [1]),
+                                      (2, 8, [8, 3]), (1, 9, [9]), (2, 33, [33, 32])])
+def test_text_encoder(gens, B, T, lens):
+    """Encoder layers on the library's kernels against the CPU layer-by-layer pass: hidden states
+    and prior statistics at the valid positions, zeros at the padded ones."""
+    cpu, gpu = gens
+    g = torch.Generator().manual_seed(T)
+    ids = torch.randint(0, 40, (B, T), generator=g)
+    lt = torch.tensor(lens)
+    want = cpu.text_encoder(ids, lt)
+    te = gpu.text_encoder
+    assert te.use_token_kernels and te._kernels_apply()
+    got = te(ids.to(DEV), lt.to(DEV))
+    for name, a, b in zip(("text_encoded", "m", "logs", "mask"), got, want):
+        assert a.shape == b.shape, name
+        err = (a.cpu() - b).abs().max().item()
+        assert err <= 2e-5 * max(1.0, b.abs().max().item()), (name, err)
+
+
+def test_rel_attention_against_the_module(gens):
+    """The attention kernel alone against MultiHeadAttention.forward on the same projected inputs,
+    with a ragged mask and more keys than one staged block."""
+    cpu, gpu = gens
+    att = cpu.text_encoder.encoder.attention_layers[2]
+    B, T = 2, 77
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 192, T, generator=g)
+    mask = synth.length_mask([77, 40], T)
+    attn_mask = mask.unsqueeze(2) * mask.unsqueeze(-1)
+    want = att(x, x, attn_mask)
+    q, k, v = att.conv_q(x), att.conv_k(x), att.conv_v(x)
+    qkv = torch.cat([q, k, v], 1).contiguous().to(DEV)
+    out = torch.empty(B, 192, T, device=DEV)
+    native.rel_attention(qkv, att.emb_rel_k[0].contiguous().to(DEV), att.emb_rel_v[0].contiguous().to(DEV),
+                         mask.reshape(B, T).contiguous().to(DEV), out, heads=2, window=4)
+    got = att.conv_o(out.cpu())
+    valid = mask.bool().expand_as(want)
+    assert (got - want)[valid].abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    with pytest.raises(native.NativeError, match="VK_ATT_MAX_LENGTH"):
+        native.rel_attention(torch.zeros(1, 576, 1025, device=DEV), att.emb_rel_k[0].contiguous().to(DEV),
+                             att.emb_rel_v[0].contiguous().to(DEV), torch.ones(1, 1025, device=DEV),
+                             torch.empty(1, 192, 1025, device=DEV), heads=2, window=4)
+
+
+def test_channel_norm():
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 192, 21, generator=g) * 3 + 1.5
+    gamma, beta = torch.randn(192, generator=g), torch.randn(192, generator=g)
+    mask = synth.length_mask([21, 20, 2], 21).reshape(3, 21)
+    want = torch.nn.functional.layer_norm(x.transpose(1, 2), (192,), gamma, beta).transpose(1, 2) * mask.unsqueeze(1)
+    out = torch.empty(3, 192, 21, device=DEV)
+    native.channel_norm(x.to(DEV), gamma.to(DEV), beta.to(DEV), mask.to(DEV), out)
+    assert (out.cpu() - want).abs().max().item() <= 1e-5
+    with pytest.raises(native.NativeError, match="192"):
+        native.channel_norm(torch.zeros(1, 64, 4, device=DEV), gamma.to(DEV), beta.to(DEV), None,
+                            torch.empty(1, 64, 4, device=DEV))
+
+
+def test_expand_prior_matches_the_alignment_matrix(gens):
+    """The gather against the reference's construction (0/1 path matrix times the statistics),
+    bit for bit: ragged token counts, zero-length tokens, an item with no frames at all."""
+    from vits_amd.module.vits_generator import generate_path, sequence_mask
+    g = torch.Generator().manual_seed(21)
+    B, Tx, C = 4, 300, 192
+    tmask = synth.length_mask([300, 120, 7, 40], Tx)
+    w = torch.randint(0, 6, (B, 1, Tx), generator=g).float() * tmask
+    w[3] = 0                                             # nothing to say: one silent frame
+    m = torch.randn(B, C, Tx, generator=g)
+    logs = torch.randn(B, C, Tx, generator=g)
+    y_len = torch.clamp_min(w.sum([1, 2]), 1).long()
+    smask = sequence_mask(y_len, None).unsqueeze(1).float()
+    path = generate_path(w, tmask.unsqueeze(2) * smask.unsqueeze(-1)).squeeze(1)
+    want_m = torch.matmul(path, m.transpose(1, 2)).transpose(1, 2)
+    want_l = torch.matmul(path, logs.transpose(1, 2)).transpose(1, 2)
+    got_m, got_l, fmask = native.expand_prior(w.reshape(B, Tx).to(DEV), m.to(DEV), logs.to(DEV), int(y_len.max()))
+    assert torch.equal(got_m.cpu(), want_m) and torch.equal(got_l.cpu(), want_l)
+    assert torch.equal(fmask.cpu(), smask.reshape(B, -1))
+    with pytest.raises(native.NativeError, match="VK_EXPAND_MAX_TOKENS"):
+        native.expand_prior(torch.ones(1, 2049, device=DEV), torch.zeros(1, 8, 2049, device=DEV),
+                            torch.zeros(1, 8, 2049, device=DEV), 2049)
+
+
+def test_frame_prior_with_and_without_the_expand_kernel(gens):
+    _, gpu = gens
+    ids = torch.tensor([synth.TTS_SENTENCE_IDS], device=DEV)
+    lens = torch.tensor([ids.shape[1]], device=DEV)
+    spk = torch.tensor([9], device=DEV)
+    nw = torch.randn(1, 2, ids.shape[1], generator=torch.Generator().manual_seed(1)).to(DEV)
+    a = gpu.frame_prior(ids, lens, spk, length_scale=3, noise_w=nw)
+    gpu.use_expand_kernel = False
+    try:
+        b = gpu.frame_prior(ids, lens, spk, length_scale=3, noise_w=nw)
+    finally:
+        del gpu.use_expand_kernel
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y)

@@ -405,6 +405,242 @@ dds_layer_kernel(LayerDev p)
     }
 }
 
+// ---- text encoder: LayerNorm over channels, windowed relative-position attention ----------
+
+struct NormDev {
+    const float* x; const float* gamma; const float* beta; const float* mask; float* out;
+    int length;
+};
+
+// out = LayerNorm_channels(x) * mask for [B, 192, T] (dense): a workgroup owns eight columns, a
+// thread two columns of one channel.
+__global__ void __launch_bounds__(NT)
+channel_norm_kernel(NormDev p)
+{
+    __shared__ float red[2][NWAVE][2];
+    const int tid = threadIdx.x, q = tid / DC, r = tid - q * DC;
+    const int T = p.length, t = (int)blockIdx.x * NC + 2 * q;
+    const int64_t row = ((int64_t)blockIdx.y * DC + r) * T;
+    float v[2], mean[2], rstd[2];
+    v[0] = t < T ? p.x[row + t] : 0.0f;
+    v[1] = t + 1 < T ? p.x[row + t + 1] : 0.0f;
+    column_norm(v, mean, rstd, red);
+    const float g = p.gamma[r], bt = p.beta[r];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (t + k < T) {
+            const float mk = p.mask ? p.mask[(int64_t)blockIdx.y * T + t + k] : 1.0f;
+            p.out[row + t + k] = ((v[k] - mean[k]) * rstd[k] * g + bt) * mk;
+        }
+}
+
+constexpr int AH = VK_ATT_HEAD_DIM;    // channels per head
+constexpr int AQ = 8;                  // queries per workgroup
+constexpr int AKB = 32;                // keys per staged block
+constexpr int AKP = AKB + 1;           // pitch of a staged key / value block
+constexpr int AWIN = VK_ATT_WINDOW;    // relative-position window
+constexpr int ANR = 2 * AWIN + 1;
+constexpr int ATHREADS = 256;
+
+struct AttDev {
+    const float* qkv; const float* emb_k; const float* emb_v; const float* mask; float* out;
+    int length, heads, s_pitch;
+};
+
+// One head's attention for eight queries: scores against all keys (the keys staged 32 at a
+// time), learned relative-position logits inside the window, key/query masking, softmax, then
+// the weighted sum of the values plus the relative-position values.
+__global__ void __launch_bounds__(ATHREADS)
+rel_attention_kernel(AttDev p)
+{
+    extern __shared__ __align__(16) float lds[];
+    float* qs = lds;                       // [AH][AQ] queries, scaled
+    float* kt = qs + AH * AQ;              // [AH][AKP] staged keys, then values
+    float* ek = kt + AH * AKP;             // [ANR][AH]
+    float* ev = ek + ANR * AH;             // [ANR][AH]
+    float* rq = ev + ANR * AH;             // [AQ][ANR] relative logits of the queries (padded to 80)
+    float* S = rq + 80;                    // [AQ][s_pitch] scores, then probabilities
+    const int tid = threadIdx.x;
+    const int T = p.length, H = p.heads, C = H * AH;
+    const int b = blockIdx.z, h = blockIdx.y, t0 = (int)blockIdx.x * AQ;
+    const float* qg = p.qkv + ((int64_t)b * 3 * C + (int64_t)h * AH) * T;
+    const float* kg = qg + (int64_t)C * T;
+    const float* vg = kg + (int64_t)C * T;
+    const float* mb = p.mask + (int64_t)b * T;
+    const float scale = 1.0f / sqrtf((float)AH);
+
+    for (int e = tid; e < AH * AQ; e += ATHREADS) {
+        const int d = e / AQ, i = e - d * AQ;
+        qs[e] = (t0 + i < T) ? qg[(int64_t)d * T + t0 + i] * scale : 0.0f;
+    }
+    for (int e = tid; e < ANR * AH; e += ATHREADS) { ek[e] = p.emb_k[e]; ev[e] = p.emb_v[e]; }
+    __syncthreads();
+    if (tid < AQ * ANR) {
+        const int i = tid / ANR, rr = tid - i * ANR;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int d = 0; d < AH; ++d) s = fmaf(qs[d * AQ + i], ek[rr * AH + d], s);
+        rq[tid] = s;
+    }
+
+    // scores: thread (query i, key lane jl)
+    const int i = tid >> 5, jl = tid & 31;
+    const int ti = t0 + i;
+    const float mi = ti < T ? mb[ti] : 0.0f;
+    constexpr int LN_ = AH * AKB / ATHREADS;            // staged elements per thread and block
+    for (int jb = 0; jb < T; jb += AKB) {
+        float tmp[LN_];
+#pragma unroll
+        for (int n = 0; n < LN_; ++n) {
+            const int e = tid + n * ATHREADS, d = e / AKB, j = e - d * AKB;
+            tmp[n] = (jb + j < T) ? kg[(int64_t)d * T + jb + j] : 0.0f;
+        }
+        __syncthreads();                                // the previous block's readers are done (and rq is written)
+#pragma unroll
+        for (int n = 0; n < LN_; ++n) {
+            const int e = tid + n * ATHREADS, d = e / AKB, j = e - d * AKB;
+            kt[d * AKP + j] = tmp[n];
+        }
+        __syncthreads();
+        const int j = jb + jl;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int d = 0; d < AH; ++d) s = fmaf(qs[d * AQ + i], kt[d * AKP + jl], s);
+        if (j < T) {
+            const int rel = j - ti;
+            if (rel >= -AWIN && rel <= AWIN) s += rq[i * ANR + rel + AWIN];
+            if (mi * mb[j] == 0.0f) s = -1e4f;
+            S[i * p.s_pitch + j] = s;
+        }
+    }
+    __syncthreads();
+
+    // softmax over the keys: 32 lanes per query
+    {
+        float* row = S + i * p.s_pitch;
+        float mx = -3.0e38f;
+        for (int j = jl; j < T; j += 32) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 32));
+        float sum = 0.0f;
+        for (int j = jl; j < T; j += 32) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 32);
+        const float inv = 1.0f / sum;
+        for (int j = jl; j < T; j += 32) row[j] *= inv;
+    }
+    __syncthreads();
+
+    // values: thread (channel d, four of the queries)
+    const int d = tid % AH, half = tid / AH;            // threads 192.. only help staging
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int jb = 0; jb < T; jb += AKB) {
+        float tmp[LN_];
+#pragma unroll
+        for (int n = 0; n < LN_; ++n) {
+            const int e = tid + n * ATHREADS, dd = e / AKB, j = e - dd * AKB;
+            tmp[n] = (jb + j < T) ? vg[(int64_t)dd * T + jb + j] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < LN_; ++n) {
+            const int e = tid + n * ATHREADS, dd = e / AKB, j = e - dd * AKB;
+            kt[dd * AKP + j] = tmp[n];
+        }
+        __syncthreads();
+        if (half < 2) {
+            const int jn = min(AKB, T - jb);
+            for (int j = 0; j < jn; ++j) {
+                const float vv = kt[d * AKP + j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = fmaf(S[(4 * half + k) * p.s_pitch + jb + j], vv, acc[k]);
+            }
+        }
+    }
+    if (half < 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tq = t0 + 4 * half + k;
+            if (tq >= T) continue;
+            float o = acc[k];
+#pragma unroll
+            for (int rr = 0; rr < ANR; ++rr) {
+                const int j = tq + rr - AWIN;
+                if (j >= 0 && j < T) o = fmaf(S[(4 * half + k) * p.s_pitch + j], ev[rr * AH + d], o);
+            }
+            p.out[((int64_t)b * C + (int64_t)h * AH + d) * T + tq] = o;
+        }
+    }
+}
+
+// ---- token level -> frame level: the hard monotonic alignment as a gather ------------------
+
+constexpr int EX_THREADS = 256;
+constexpr int EX_CH = 8;                       // channels per workgroup
+constexpr int EX_PER = VK_EXPAND_MAX_TOKENS / EX_THREADS;
+
+struct ExpandDev {
+    const float* dur; const float* m; const float* logs; float* m_out; float* logs_out; float* frame_mask;
+    int channels, tokens, frames;
+};
+
+// Frame y belongs to token x iff cum[x - 1] <= y < cum[x] (cum = running sum of the durations).
+// Every workgroup scans the durations of its batch item (a few hundred values), each thread
+// finds the token of its frame by bisection and copies EX_CH channels of both statistics.
+__global__ void __launch_bounds__(EX_THREADS)
+expand_prior_kernel(ExpandDev p)
+{
+    __shared__ float cum[VK_EXPAND_MAX_TOKENS];
+    __shared__ float partial[EX_THREADS];
+    const int tid = threadIdx.x, b = blockIdx.z, c0 = (int)blockIdx.y * EX_CH;
+    const int Tx = p.tokens, Ty = p.frames;
+    const int per = (Tx + EX_THREADS - 1) / EX_THREADS;
+    float loc[EX_PER], s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EX_PER; ++k) {
+        const int idx = tid * per + k;
+        s += (k < per && idx < Tx) ? p.dur[(int64_t)b * Tx + idx] : 0.0f;
+        loc[k] = s;
+    }
+    partial[tid] = s;
+    __syncthreads();
+    float base = 0.0f;
+    for (int i = 0; i < tid; ++i) base += partial[i];
+#pragma unroll
+    for (int k = 0; k < EX_PER; ++k) {
+        const int idx = tid * per + k;
+        if (k < per && idx < Tx) cum[idx] = base + loc[k];
+    }
+    __syncthreads();
+    const float total = cum[Tx - 1];
+    const int y = (int)blockIdx.x * EX_THREADS + tid;
+    if (y >= Ty) return;
+    const float fy = (float)y;
+    int lo = 0, hi = Tx;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] > fy) hi = mid; else lo = mid + 1;
+    }
+    const bool valid = fy < total;
+    const int x = valid ? lo : 0;
+    if (c0 == 0) p.frame_mask[(int64_t)b * Ty + y] = fy < fmaxf(total, 1.0f) ? 1.0f : 0.0f;
+    float vm[EX_CH], vl[EX_CH];
+#pragma unroll
+    for (int c = 0; c < EX_CH; ++c) {
+        const bool ok = valid && c0 + c < p.channels;
+        const int64_t src = ((int64_t)b * p.channels + c0 + c) * Tx + x;
+        vm[c] = ok ? p.m[src] : 0.0f;
+        vl[c] = ok ? p.logs[src] : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < EX_CH; ++c)
+        if (c0 + c < p.channels) {
+            const int64_t dst = ((int64_t)b * p.channels + c0 + c) * Ty + y;
+            p.m_out[dst] = vm[c];
+            p.logs_out[dst] = vl[c];
+        }
+}
+
 bool overlap(const void* p, int64_t pn, const void* q, int64_t qn)
 {
     const char* a = (const char*)p; const char* b = (const char*)q;
@@ -478,6 +714,57 @@ int dds_launch(const vk_dds_args* a, void* stream, bool coupling, const char* wh
 }
 
 }  // namespace
+
+extern "C" int vk_channel_norm(const float* x, const float* gamma, const float* beta, const float* mask, float* out,
+                               int batch, int channels, int length, void* stream)
+{
+    if (!x || !gamma || !beta || !out || batch <= 0 || length <= 0)
+        return vk_fail(VK_E_ARG, "vk_channel_norm: null pointer or non-positive size");
+    if (channels != DC) return vk_fail(VK_E_UNSUPPORTED, "vk_channel_norm: channels must be 192");
+    if (batch > 65535) return vk_fail(VK_E_UNSUPPORTED, "vk_channel_norm: batch > 65535");
+    NormDev d{x, gamma, beta, mask, out, length};
+    dim3 grid((unsigned)((length + NC - 1) / NC), (unsigned)batch);
+    hipLaunchKernelGGL(channel_norm_kernel, grid, dim3(NT), 0, (hipStream_t)stream, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vk_fail(VK_E_LAUNCH, hipGetErrorString(e));
+    return VK_OK;
+}
+
+extern "C" int vk_rel_attention(const float* qkv, const float* emb_k, const float* emb_v, const float* mask, float* out,
+                                int batch, int heads, int head_dim, int window, int length, void* stream)
+{
+    if (!qkv || !emb_k || !emb_v || !mask || !out || batch <= 0 || heads <= 0 || length <= 0)
+        return vk_fail(VK_E_ARG, "vk_rel_attention: null pointer or non-positive size");
+    if (head_dim != AH || window != AWIN)
+        return vk_fail(VK_E_UNSUPPORTED, "vk_rel_attention: head_dim must be 96 and window 4");
+    if (length > VK_ATT_MAX_LENGTH) return vk_fail(VK_E_UNSUPPORTED, "vk_rel_attention: sequence longer than VK_ATT_MAX_LENGTH");
+    if (batch > 65535 || heads > 65535) return vk_fail(VK_E_UNSUPPORTED, "vk_rel_attention: batch or heads > 65535");
+    AttDev d{qkv, emb_k, emb_v, mask, out, length, heads, (length + 3) & ~3};
+    const size_t ldsb = (size_t)(AH * AQ + AH * AKP + 2 * ANR * AH + 80 + AQ * d.s_pitch) * sizeof(float);
+    static std::atomic<unsigned long long> raised{0};
+    hipError_t e = vk_allow_lds(rel_attention_kernel, ldsb, raised);
+    if (e != hipSuccess) return vk_fail(VK_E_LAUNCH, hipGetErrorString(e));
+    dim3 grid((unsigned)((length + AQ - 1) / AQ), (unsigned)heads, (unsigned)batch);
+    hipLaunchKernelGGL(rel_attention_kernel, grid, dim3(ATHREADS), ldsb, (hipStream_t)stream, d);
+    e = hipGetLastError();
+    if (e != hipSuccess) return vk_fail(VK_E_LAUNCH, hipGetErrorString(e));
+    return VK_OK;
+}
+
+extern "C" int vk_expand_prior(const float* durations, const float* m, const float* logs, float* m_out, float* logs_out,
+                               float* frame_mask, int batch, int channels, int tokens, int frames, void* stream)
+{
+    if (!durations || !m || !logs || !m_out || !logs_out || !frame_mask || batch <= 0 || channels <= 0 || tokens <= 0 || frames <= 0)
+        return vk_fail(VK_E_ARG, "vk_expand_prior: null pointer or non-positive size");
+    if (tokens > VK_EXPAND_MAX_TOKENS) return vk_fail(VK_E_UNSUPPORTED, "vk_expand_prior: more than VK_EXPAND_MAX_TOKENS tokens");
+    if (batch > 65535) return vk_fail(VK_E_UNSUPPORTED, "vk_expand_prior: batch > 65535");
+    ExpandDev d{durations, m, logs, m_out, logs_out, frame_mask, channels, tokens, frames};
+    dim3 grid((unsigned)((frames + EX_THREADS - 1) / EX_THREADS), (unsigned)((channels + EX_CH - 1) / EX_CH), (unsigned)batch);
+    hipLaunchKernelGGL(expand_prior_kernel, grid, dim3(EX_THREADS), 0, (hipStream_t)stream, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vk_fail(VK_E_LAUNCH, hipGetErrorString(e));
+    return VK_OK;
+}
 
 extern "C" int64_t vk_dds_workspace_bytes(int batch, int length)
 {

@@ -13,6 +13,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .. import native
 from .model_component.decoder import Decoder
 from .model_component.flow import Flow
 from .model_component.posterior_encoder import PosteriorEncoder
@@ -131,6 +132,7 @@ class VitsGenerator(HotPathGenerator):
     # durations has data-dependent shapes and stays eager.  VITS_AMD_FRONT_GRAPH=0, or
     # ``use_front_graph = False`` on an instance, keeps this half eager too.
     use_front_graph = os.environ.get("VITS_AMD_FRONT_GRAPH", "1") != "0"
+    use_expand_kernel = os.environ.get("VITS_AMD_TOKEN_KERNELS", "1") != "0"   # 0: alignment matrix + matmul in PyTorch
     max_front_graphs = 16           # captured shapes kept per instance (least recently used goes first)
 
     def _token_stage(self, text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w):
@@ -185,6 +187,13 @@ class VitsGenerator(HotPathGenerator):
         stage = self._token_stage_graphed if (self.use_front_graph and text_padded.is_cuda) else self._token_stage
         m_p, logs_p, text_mask, w_ceil, g = stage(text_padded, text_lengths, speaker_id, noise_w, length_scale,
                                                   noise_scale_w)
+        if m_p.is_cuda and self.use_expand_kernel and m_p.shape[2] <= native.EXPAND_MAX_TOKENS:
+            # the alignment as a gather: the only host round trip is the number of frames
+            frames = int(torch.clamp_min(w_ceil.sum([1, 2]), 1).max().item())
+            B, _, Tx = w_ceil.shape
+            m_f, logs_f, fmask = native.expand_prior(w_ceil.reshape(B, Tx).float().contiguous(),
+                                                     m_p.float().contiguous(), logs_p.float().contiguous(), frames)
+            return m_f, logs_f, fmask.unsqueeze(1).to(text_mask.dtype), g
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
         spec_mask = torch.unsqueeze(sequence_mask(y_lengths, None), 1).to(text_mask.dtype)
         node_mask = torch.unsqueeze(text_mask, 2) * torch.unsqueeze(spec_mask, -1)

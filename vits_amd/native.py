@@ -171,6 +171,9 @@ def lib():
         L.vk_conv1d_static.argtypes = [C.POINTER(ConvArgs), C.c_void_p]
         L.vk_conv1d_workspace_bytes.argtypes = [C.POINTER(ConvArgs)]
         L.vk_conv1d_workspace_bytes.restype = C.c_int64
+        L.vk_channel_norm.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.vk_rel_attention.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.vk_expand_prior.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.vk_dds_workspace_bytes.argtypes = [C.c_int, C.c_int]
         L.vk_dds_workspace_bytes.restype = C.c_int64
         L.vk_dds_condition.argtypes = [C.POINTER(DdsArgs), C.c_void_p]
@@ -531,6 +534,53 @@ def dds_coupling(z, pre_w, pre_b, g, layers, n_layers, taps, proj_wt, proj_b, ma
     L, sp = lib(), stream_ptr(z.device)
     check(_timed("dds_coupling", flops, 4.0 * B * DDS_CHANNELS * T, z.device,
                  lambda: L.vk_dds_coupling(C.byref(a), sp), f"B{B} T{T}"), "vk_dds_coupling")
+
+
+ATT_MAX_LENGTH = 1024
+
+
+def channel_norm(x, gamma, beta, mask, out):
+    """out = LayerNorm over channels of x [B, 192, T] (dense) times mask [B, T] (or None)."""
+    assert x.is_cuda and x.is_contiguous() and out.is_contiguous() and x.dtype == torch.float32
+    B, Cn, T = x.shape
+    L, sp = lib(), stream_ptr(x.device)
+    check(_timed("channel_norm", 8.0 * x.numel(), 8.0 * x.numel(), x.device,
+                 lambda: L.vk_channel_norm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           mask.data_ptr() if mask is not None else None, out.data_ptr(),
+                                           B, Cn, T, sp), f"B{B} T{T}"), "vk_channel_norm")
+
+
+def rel_attention(qkv, emb_k, emb_v, mask, out, *, heads, window):
+    """Windowed relative-position attention: qkv [B, 3 * C, T] (queries, keys, values), out [B, C, T]."""
+    assert qkv.is_cuda and qkv.is_contiguous() and out.is_contiguous() and mask.is_contiguous()
+    assert emb_k.is_contiguous() and emb_v.is_contiguous()
+    B, C3, T = qkv.shape
+    head_dim = C3 // 3 // heads
+    L, sp = lib(), stream_ptr(qkv.device)
+    check(_timed("rel_attention", 4.0 * B * heads * T * T * head_dim, 4.0 * (qkv.numel() + out.numel()), qkv.device,
+                 lambda: L.vk_rel_attention(qkv.data_ptr(), emb_k.data_ptr(), emb_v.data_ptr(), mask.data_ptr(),
+                                            out.data_ptr(), B, heads, head_dim, window, T, sp), f"B{B} T{T}"),
+          "vk_rel_attention")
+
+
+EXPAND_MAX_TOKENS = 2048
+
+
+def expand_prior(durations, m, logs, frames):
+    """Token-level (m, logs) [B, C, Tx] spread over ``frames`` frames by the whole-number
+    ``durations`` [B, Tx]: returns (m_frames, logs_frames [B, C, frames], frame_mask [B, frames])."""
+    assert m.is_cuda and m.is_contiguous() and logs.is_contiguous() and durations.is_contiguous()
+    assert m.dtype == logs.dtype == durations.dtype == torch.float32
+    B, Cn, Tx = m.shape
+    m_out = torch.empty(B, Cn, frames, device=m.device, dtype=torch.float32)
+    logs_out = torch.empty_like(m_out)
+    fmask = torch.empty(B, frames, device=m.device, dtype=torch.float32)
+    L, sp = lib(), stream_ptr(m.device)
+    check(_timed("expand_prior", 0.0, 16.0 * B * Cn * frames, m.device,
+                 lambda: L.vk_expand_prior(durations.data_ptr(), m.data_ptr(), logs.data_ptr(), m_out.data_ptr(),
+                                           logs_out.data_ptr(), fmask.data_ptr(), B, Cn, Tx, frames, sp),
+                 f"B{B} Tx{Tx} Ty{frames}"), "vk_expand_prior")
+    return m_out, logs_out, fmask
 
 
 def speaker_linear(g, w, bias, out):
