@@ -105,6 +105,20 @@ class PackedConv:
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+# Bumped whenever a Parameter is (re)registered on any module: the caches below keep a flat list of
+# their module's parameters (walking the module tree costs several times more than checking the
+# parameters themselves) and refresh it when this moves.
+_registrations = [0]
+
+
+def _count_registration(module, name, param):
+    _registrations[0] += 1
+    return None
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_count_registration)
+
+
 class PlanCache:
     """Rebuilds a module's packed weights when its parameters or device change."""
 
@@ -113,9 +127,14 @@ class PlanCache:
         self._builder = builder
         self._key = None
         self._plan = None
+        self._params = None
+        self._seen = -1
 
     def get(self, device):
-        key = (str(device), precision()) + tuple((p.data_ptr(), p._version) for p in self._module.parameters())
+        if self._seen != _registrations[0]:
+            self._params = list(self._module.parameters())
+            self._seen = _registrations[0]
+        key = (str(device), precision()) + tuple((p.data_ptr(), p._version) for p in self._params)
         if key != self._key:
             with torch.no_grad():
                 self._plan = self._builder(device)

@@ -14,6 +14,8 @@ import torch
 
 class GraphedCall:
     def __init__(self, fn, *example_inputs, warmup: int = 3):
+        from . import native
+        native.branch_streams(example_inputs[0].device)                 # before the capture's own streams exist
         self._static_in = [x.clone() for x in example_inputs]
         stream = torch.cuda.Stream(device=self._static_in[0].device)
         stream.wait_stream(torch.cuda.current_stream(self._static_in[0].device))
@@ -21,7 +23,6 @@ class GraphedCall:
             for _ in range(warmup):
                 fn(*self._static_in)
         torch.cuda.current_stream(self._static_in[0].device).wait_stream(stream)
-        from . import native
         native.ensure_capture_workspace(self._static_in[0].device)      # scratch of split channel loops, made outside the capture
         self._graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self._graph):

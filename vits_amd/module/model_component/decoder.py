@@ -176,7 +176,6 @@ class DecoderPlan:
                              s, wt.shape[1]))
         self.resblocks = [rb.plan(device) for rb in dec.resblocks]
         self.stages = [self._fused_stage(dec, i, device) for i in range(dec.num_deconvs)]
-        self.side_streams = None            # created on first use by a small-batch forward
         self.post_w = dec.conv1d_post.weight.detach().to(device)[0].contiguous()    # [C, taps]
 
 
@@ -263,13 +262,12 @@ class Decoder(nn.Module):
     def _run_branches_concurrently(self, plan, stage, xu, xs, epis):
         nrb = self.num_resnet_blocks
         main = torch.cuda.current_stream(xu.device)
-        if plan.side_streams is None or len(plan.side_streams) < nrb - 1:
-            plan.side_streams = [torch.cuda.Stream(device=xu.device) for _ in range(nrb - 1)]
+        side_streams = native.branch_streams(xu.device, nrb - 1)
         fork = torch.cuda.Event()
         fork.record(main)
         prev_done = None
         for j in range(nrb):
-            stream = main if j == 0 else plan.side_streams[j - 1]
+            stream = main if j == 0 else side_streams[j - 1]
             if j > 0:
                 stream.wait_event(fork)
             with torch.cuda.stream(stream):

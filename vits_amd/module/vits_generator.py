@@ -147,8 +147,12 @@ class VitsGenerator(HotPathGenerator):
     def _front_weights_key(self):
         """Where the captured kernels read their weights from: a graph is only good while the
         parameters stay in the storage they had at capture (in-place loads keep it, .to() does not)."""
-        mods = (self.text_encoder, self.stochastic_duration_predictor, self.speaker_embedding)
-        return hash(tuple(p.data_ptr() for m in mods for p in m.parameters()))
+        from .. import engine
+        if getattr(self, "_front_params_seen", -1) != engine._registrations[0]:
+            mods = (self.text_encoder, self.stochastic_duration_predictor, self.speaker_embedding)
+            self._front_params = [p for m in mods for p in m.parameters()]     # the tree walk is the costly part
+            self._front_params_seen = engine._registrations[0]
+        return hash(tuple(p.data_ptr() for p in self._front_params))
 
     def _token_stage_graphed(self, text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w):
         from ..graphs import GraphedCall

@@ -221,8 +221,15 @@ def pair_info(channels: int, precision: int = 0):
     return _pair_cache[key]
 
 
+def _device_index(device) -> int:
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    return torch.cuda.current_device() if idx is None else idx
+
+
 def stream_ptr(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """The raw hipStream_t of torch's current stream on ``device`` (the direct query: building a
+    torch.cuda.Stream object per launch costs several microseconds of host time)."""
+    return torch._C._cuda_getCurrentRawStream(_device_index(device))
 
 
 def _view(t: torch.Tensor):
@@ -295,12 +302,13 @@ def workspace(device):
     counters zero.  A stream that is being captured into a graph takes the device's capture
     workspace (made ahead of the capture by ``ensure_capture_workspace``): capture streams come
     and go, and a workspace made during capture would live in the graph's private pool."""
-    device = torch.device(device)
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    index = _device_index(device)
+    key = (index, torch._C._cuda_getCurrentRawStream(index))
     ws = _workspaces.get(key)
     if ws is None:
+        device = torch.device("cuda", index)
         if torch.cuda.is_current_stream_capturing():
-            ws = _workspaces.get((device.index, "capture"))
+            ws = _workspaces.get((index, "capture"))
             if ws is None:
                 raise NativeError("no capture workspace: call native.ensure_capture_workspace(device) before the capture")
             return ws
@@ -309,13 +317,33 @@ def workspace(device):
     return ws
 
 
+_branch_streams = {}
+
+
+def branch_streams(device, n: int = 2):
+    """``n`` side streams per device for launches that may overlap with the current stream (the
+    resblocks of a decoder stage at small batch).  Made once and bound to hardware queues at once
+    (a first tiny launch): the GPU exposes four hardware queues per process and streams take them
+    in the order they first launch, so side streams that come to life after other streams (a graph
+    capture makes two) can land on the queue of the stream they are meant to overlap with."""
+    index = _device_index(device)
+    have = _branch_streams.setdefault(index, [])
+    while len(have) < n:
+        st = torch.cuda.Stream(device=torch.device("cuda", index))
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=torch.device("cuda", index))
+        have.append(st)
+    return have[:n]
+
+
 def ensure_capture_workspace(device):
     """Make the workspace that launches on a capturing stream use (see ``workspace``).  Call it
     outside any capture; graphs captured on one device share it, so they must not replay
     concurrently with each other."""
-    device = torch.device(device)
-    key = (device.index, "capture")
+    index = _device_index(device)
+    key = (index, "capture")
     if key not in _workspaces:
+        device = torch.device("cuda", index)
         _workspaces[key] = torch.zeros(WS_BYTES // 4, dtype=torch.float32, device=device)
         torch.cuda.synchronize(device)
     return _workspaces[key]
@@ -367,10 +395,11 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     L = lib()
     if precision == PREC_F32 and blocks < 512 and SPLIT_SMALL_LAUNCHES and not static_scratch:
         # far too few workgroups for 256 CUs: with scratch the library splits the channel loop
-        need = L.vk_conv1d_workspace_bytes(C.byref(a))
-        if need > 0:
+        # (it decides itself whether to; under capture only launches that will split ask for the
+        # capture workspace, so a foreign capture without one keeps working for the others)
+        if not torch.cuda.is_current_stream_capturing() or L.vk_conv1d_workspace_bytes(C.byref(a)) > 0:
             ws = workspace(x.device)
-            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+            a.workspace, a.workspace_bytes = ws.data_ptr(), WS_BYTES
     rows = c_out * up_stride if epilogue == EPI_UPSAMPLE else c_out
     flops = 2.0 * x.shape[0] * x.shape[2] * rows * c_in * taps
     family = (f"conv_{('mfma', 'bf16', 'split')[precision]}"
