@@ -196,3 +196,31 @@ def test_frame_prior_with_and_without_the_expand_kernel(gens):
         del gpu.use_expand_kernel
     for x, y in zip(a, b):
         assert x.shape == y.shape and torch.equal(x, y)
+
+
+def test_ragged_batch_text_to_speech_front(gens):
+    """Three sentences of different lengths in one batch: durations identical to the CPU
+    layer-by-layer pass, frame-level prior within the fp32 gate, frame masks identical; then the
+    whole text_to_speech against the CPU front half + oracle tail on the first item."""
+    from oracle import vits_oracle as O
+    cpu, gpu = gens
+    g = torch.Generator().manual_seed(77)
+    lens = [43, 20, 7]
+    ids = torch.randint(0, 40, (3, 43), generator=g)
+    ids[0] = torch.tensor(synth.TTS_SENTENCE_IDS)
+    lt = torch.tensor(lens)
+    spk = torch.tensor([9, 57, 3])
+    nw = torch.randn(3, 2, 43, generator=g)
+    want = cpu.frame_prior(ids, lt, spk, length_scale=2, noise_w=nw)
+    got = gpu.frame_prior(ids.to(DEV), lt.to(DEV), spk.to(DEV), length_scale=2, noise_w=nw.to(DEV))
+    assert got[0].shape == want[0].shape, "a duration rounded differently"
+    assert torch.equal(got[2].cpu(), want[2])
+    for name, a, b in zip(("m_p", "logs_p"), got[:2], want[:2]):
+        assert (a.cpu() - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), name
+    nz = torch.randn(want[0].shape, generator=g)
+    wav = gpu.text_to_speech(ids.to(DEV), lt.to(DEV), spk.to(DEV), length_scale=2, noise_w=nw.to(DEV),
+                             noise_z=nz.to(DEV))
+    sd = cpu.state_dict()
+    _, ref = O.tts_tail(want[0], want[1], want[2], nz, want[3], sd)
+    assert wav.shape == ref.shape
+    assert (wav.cpu() - ref).abs().max().item() <= 1e-4
