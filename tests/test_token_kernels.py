@@ -224,3 +224,15 @@ def test_ragged_batch_text_to_speech_front(gens):
     _, ref = O.tts_tail(want[0], want[1], want[2], nz, want[3], sd)
     assert wav.shape == ref.shape
     assert (wav.cpu() - ref).abs().max().item() <= 1e-4
+
+
+def test_text_encoder_beyond_the_attention_limit_uses_the_pytorch_form(gens):
+    """More tokens than the attention kernel holds in LDS: the layer-by-layer form runs instead."""
+    cpu, gpu = gens
+    T = native.ATT_MAX_LENGTH + 6
+    ids = torch.randint(0, 40, (1, T), generator=torch.Generator().manual_seed(2))
+    lt = torch.tensor([T])
+    want = cpu.text_encoder(ids, lt)
+    got = gpu.text_encoder(ids.to(DEV), lt.to(DEV))
+    for a, b in zip(got, want):
+        assert (a.cpu() - b).abs().max().item() <= 5e-5 * max(1.0, b.abs().max().item())

@@ -189,6 +189,8 @@ def lib():
                 raise NativeError(f"{mirror.__name__} is {C.sizeof(mirror)} bytes here, "
                                   f"{L.vk_sizeof_args(which)} in the library: native.py is out of step with the header")
         _lib = L
+        if torch.cuda.is_initialized():          # take the side streams' hardware queues before anybody captures a graph
+            branch_streams(torch.device("cuda", torch.cuda.current_device()))
     return _lib
 
 
