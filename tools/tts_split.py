@@ -2,7 +2,7 @@
 """Where one text_to_speech call (config 1) spends its time: token-level graph, path expansion, flow + decoder."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vits_amd import synth
 from vits_amd.graphs import GraphedCall

@@ -230,6 +230,16 @@ class StochasticDurationPredictor(nn.Module):
         self.cond = nn.Conv1d(speaker_id_embedding_dim, filter_channels, 1)
         self._plans = PlanCache(self, lambda dev: SdpPlan(self, dev))
 
+    def _kernels_apply(self) -> bool:
+        """The token kernels are built for the reference's sizes: 192 channels, 3-tap stacks of up
+        to three layers, 10 spline bins; anything else takes the layer-by-layer form."""
+        if not self.use_token_kernels or len(self.flows) <= 3:
+            return False
+        stacks = [self.convs] + [f.convs for f in self.flows if isinstance(f, ConvFlow)]
+        return (self.pre.in_channels == native.DDS_CHANNELS and self.pre.out_channels == native.DDS_CHANNELS
+                and all(d.n_layers <= 3 and d.convs_sep[0].kernel_size[0] == 3 for d in stacks)
+                and all(f.num_bins == 10 and f.half_channels == 1 for f in self.flows if isinstance(f, ConvFlow)))
+
     def _reverse_on_token_kernels(self, text_encoded, text_mask, speaker_id_embedded, noise_scale, noise):
         plan = self._plans.get(text_encoded.device)
         B, H, T = text_encoded.shape
@@ -263,7 +273,7 @@ class StochasticDurationPredictor(nn.Module):
         standard normal) replaces the internal ``torch.randn`` draw."""
         if not reverse:
             raise NotImplementedError("the training direction of the duration predictor is out of scope")
-        if text_encoded.is_cuda and self.use_token_kernels and len(self.flows) > 3:
+        if text_encoded.is_cuda and self._kernels_apply():
             if noise is None:
                 noise = torch.randn(text_encoded.size(0), 2, text_encoded.size(2)).to(
                     device=text_encoded.device, dtype=text_encoded.dtype)

@@ -181,7 +181,8 @@ class TextEncoder(nn.Module):
         att = self.encoder.attention_layers[0]
         ffn = self.encoder.ffn_layers[0]
         return (self.use_token_kernels and self.phoneme_embedding_dim == native.DDS_CHANNELS
-                and att.k_channels == 96 and att.window_size == 4 and ffn.kernel_size % 2 == 1)
+                and att.k_channels == 96 and att.window_size == 4 and ffn.kernel_size % 2 == 1
+                and ffn.conv_1.out_channels % 64 == 0)
 
     def _forward_on_kernels(self, x, text_mask):
         """Encoder layers and the projection on the library's kernels.  Padded columns are kept at
