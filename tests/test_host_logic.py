@@ -192,6 +192,38 @@ def test_argument_validation_without_gpu():
     assert L.vk_conv1d_lds_bytes(ctypes.byref(_conv_args(out=0x10000000, taps=1, pad=0, c_out=64))) == -1
 
 
+def test_token_kernel_argument_validation_without_gpu():
+    """The token-level entry points check their arguments on the host before any launch."""
+    L = native.lib()
+    P = 0x10000000                                                     # never dereferenced
+    assert L.vk_channel_norm(None, None, None, None, None, 1, 192, 4, None) == -1
+    assert L.vk_channel_norm(P, P, P, None, P, 1, 64, 4, None) == -2 and b"192" in L.vk_last_error()
+    assert L.vk_rel_attention(P, P, P, P, P, 1, 2, 96, 4, 0, None) == -1
+    assert L.vk_rel_attention(P, P, P, P, P, 1, 2, 64, 4, 10, None) == -2
+    assert L.vk_rel_attention(P, P, P, P, P, 1, 2, 96, 4, 1025, None) == -2 and b"VK_ATT_MAX_LENGTH" in L.vk_last_error()
+    assert L.vk_expand_prior(P, P, P, P, P, None, 1, 192, 10, 20, None) == -1
+    assert L.vk_expand_prior(P, P, P, P, P, P, 1, 192, 4096, 20, None) == -2
+    assert L.vk_dds_workspace_bytes(2, 100) == 2 * 2 * 192 * 100 * 4
+    a = native.DdsArgs()
+    assert L.vk_dds_condition(ctypes.byref(a), None) == -1 and b"null" in L.vk_last_error()
+    for f in ("x", "pre_wt", "pre_b", "layers", "proj_wt", "proj_b", "mask"):
+        setattr(a, f, P)
+    a.out = 0x20000000
+    a.batch, a.length, a.n_layers, a.taps = 1, 50, 3, 3
+    a.x_bstride, a.x_cstride, a.out_bstride, a.out_cstride = 192 * 50, 50, 192 * 50, 50
+    assert L.vk_dds_condition(ctypes.byref(a), None) == -4 and b"workspace" in L.vk_last_error()
+    a.workspace, a.workspace_bytes = 0x30000000, 100                   # too small
+    assert L.vk_dds_condition(ctypes.byref(a), None) == -4
+    a.taps = 5
+    assert L.vk_dds_condition(ctypes.byref(a), None) == -2
+    a.taps = 3
+    a.workspace_bytes = L.vk_dds_workspace_bytes(1, 50)
+    a.out = P + 64                                                     # on top of the input
+    assert L.vk_dds_condition(ctypes.byref(a), None) == -1 and b"overlaps" in L.vk_last_error()
+    a.out = 0x20000000
+    assert L.vk_dds_coupling(ctypes.byref(a), None) == -1 and b"add_map" in L.vk_last_error()
+
+
 def test_vector_staging_falls_back_when_its_alignment_slack_does_not_fit():
     """halo 64 with an odd left padding: the 16-byte stager would need 68 extra columns, the
     4-byte stager fits in the 64-column slack of the LDS row."""
