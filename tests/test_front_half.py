@@ -1,5 +1,6 @@
-"""The stock-PyTorch front half of text_to_speech (text encoder, stochastic duration
-predictor in reverse, path expansion) and the complete generator's state_dict layout,
+"""The layer-by-layer PyTorch form of the front half of text_to_speech (text encoder, stochastic
+duration predictor in reverse, path expansion; what CPU tensors run, and what the GPU token kernels
+are compared with in test_token_kernels.py) and the complete generator's state_dict layout,
 against vectors captured from the reference (tests/golden/make_golden.py).  CPU only."""
 import json
 import os

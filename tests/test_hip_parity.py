@@ -195,7 +195,7 @@ def test_full_size_decoder_checksums(sd, golden_dir):
 
 
 def test_text_to_speech_end_to_end(golden_dir):
-    """Whole VitsGenerator.text_to_speech on the GPU (stock-PyTorch front half + HIP hot path)
+    """Whole VitsGenerator.text_to_speech on the GPU (token-level kernels + HIP hot path)
     against the reference's waveform for the same 43-token sentence and pinned noise."""
     from vits_amd.module.vits_generator import VitsGenerator
     g11 = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "g11_tts.npz")).items()}
@@ -226,7 +226,7 @@ def test_graph_replay_matches_eager(sd):
 
 
 def test_front_half_graph_replay_matches_eager():
-    """Token-level half (text encoder + duration predictor, stock PyTorch kernels) captured into
+    """Token-level half (text encoder + duration predictor) captured into
     a HIP graph and replayed with other tokens, speaker and noise: the same kernels in the same
     order as the eager path, so the token-level prior and the durations are identical."""
     from vits_amd.module.vits_generator import VitsGenerator

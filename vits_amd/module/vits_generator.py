@@ -95,8 +95,8 @@ class VitsGenerator(HotPathGenerator):
     """Drop-in for the reference's ``VitsGenerator(n_phoneme, n_speakers)``
     (/root/reference/module/vits_generator.py:67-197), inference methods only: the complete
     ``netG_cpu.pth`` loads with ``strict=True``; ``text_to_speech`` runs the text encoder,
-    duration predictor and path expansion in stock PyTorch (:169-182) and the hot path
-    (:184-186) on the HIP kernels; ``voice_conversion`` is inherited.  The training
+    duration predictor and path expansion (:169-182) on the token-level kernels and the hot path
+    (:184-186) on the convolution kernels; ``voice_conversion`` is inherited.  The training
     ``forward`` (:127-166) is out of scope."""
 
     def __init__(self, n_phoneme, n_speakers):
@@ -125,11 +125,10 @@ class VitsGenerator(HotPathGenerator):
     def forward(self, *args, **kwargs):
         raise NotImplementedError("training forward (vits_generator.py:127-166) is out of scope of the inference build")
 
-    # The token-level half (text encoder, duration predictor) is some 400 tiny stock-PyTorch
-    # launches whose cost is host launch time (about 7.5 ms for one sentence against about 1.5 ms
-    # of GPU work).  It is captured once per (batch, tokens, scales) into a HIP graph and
-    # replayed (bit-identical to the eager run: same kernels, same order); everything after the
-    # durations has data-dependent shapes and stays eager.  VITS_AMD_FRONT_GRAPH=0, or
+    # The token-level half (text encoder, duration predictor) is some 60 small launches, each bound
+    # by latency.  It is captured once per (batch, tokens, scales) into a HIP graph and replayed
+    # (bit-identical to the eager run: same kernels, same order); everything after the durations
+    # has data-dependent shapes and stays eager.  VITS_AMD_FRONT_GRAPH=0, or
     # ``use_front_graph = False`` on an instance, keeps this half eager too.
     use_front_graph = os.environ.get("VITS_AMD_FRONT_GRAPH", "1") != "0"
     use_expand_kernel = os.environ.get("VITS_AMD_TOKEN_KERNELS", "1") != "0"   # 0: alignment matrix + matmul in PyTorch
