@@ -120,7 +120,7 @@ typedef struct {
     int32_t precision;    /* VK_PREC_* (selects the packed weight format too) */
     int32_t narrow;       /* 1: half the family's time tile (twice the workgroups, same packed weights);
                              for launches too small to fill the GPU.  VK_PREC_F32 only, ignored otherwise */
-    /* Scratch for launches too small to fill the GPU (VK_PREC_F32 only): with it, such a launch
+    /* Scratch for launches too small to fill the GPU (VK_PREC_F32 and VK_PREC_F32_SPLIT): with it, such a launch
      * splits the channel loop over up to 8 workgroups per output tile; each writes its partial
      * accumulators here and the last one to arrive adds them in a fixed order and runs the
      * epilogue.  NULL: no split.  vk_conv1d_workspace_bytes says how much a launch uses.  The
@@ -151,8 +151,8 @@ int64_t     vk_conv1d_lds_bytes(const vk_conv_args* a);
 int vk_conv1d(const vk_conv_args* a, void* stream);
 
 /* Bytes of `workspace` this launch would use (counters included), 0 if it does not split, or a
- * negative VK_E_* code.  A launch splits when it has fewer than 512 workgroups and at least 4
- * channel chunks; never more than VK_WS_MAX_BYTES. */
+ * negative VK_E_* code.  A launch splits when it has fewer than 512 workgroups (VK_PREC_F32_SPLIT: 128)
+ * and at least 4 channel chunks; never more than VK_WS_MAX_BYTES. */
 #define VK_WS_MAX_BYTES (VK_WS_COUNTER_BYTES + (64 << 20))
 int64_t vk_conv1d_workspace_bytes(const vk_conv_args* a);
 

@@ -612,6 +612,45 @@ def test_split_channel_loop_matches_the_single_workgroup_form(cin, cout, k, dil,
     assert int(ws[:native.WS_COUNTER_BYTES // 4].view(torch.int32).abs().max()) == 0
 
 
+@pytest.mark.parametrize("cin,cout,k,dil,B,L", [
+    (256, 256, 11, 1, 1, 2064),      # 17 tiles x 2 row blocks = 34 jobs: 4 shares of the 16 chunks
+    (256, 256, 3, 5, 1, 70),
+    (192, 384, 5, 1, 1, 237),        # 12 chunks: the share count must divide them
+    (128, 128, 7, 1, 2, 500),
+    (64, 64, 7, 3, 1, 300),          # exactly 4 chunks: 2 shares
+])
+def test_split_channel_loop_of_the_sliced_fp32_kernel(cin, cout, k, dil, B, L, monkeypatch):
+    """The persistent sliced-fp32 kernel with its channel chunks shared out over several jobs per
+    output tile: fp32-level agreement with the fp64 result and with the unsplit launch, run-to-run
+    identical, counters left at zero."""
+    x = _rand(B, cin, L, seed=321).to(DEV)
+    w = _rand(cout, cin, k, seed=322) / (cin * k) ** 0.5
+    bias = _rand(cout, seed=323).to(DEV)
+    res = _rand(B, cout, L, seed=324).to(DEV)
+    pad = (k - 1) * dil // 2
+    tile = choose_tile(cout)
+    wp = _pack_split(w, tile)
+
+    def run(split):
+        monkeypatch.setattr(native, "SPLIT_SMALL_LAUNCHES", split)
+        out = torch.full((B, cout, L), float("nan"), device=DEV)
+        native.conv1d(x, wp, out, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                      epilogue=native.EPI_RESID, bias=bias, res=res, act_in=True, in_slope=0.1)
+        return out
+
+    one, two, three = run(False), run(True), run(True)
+    ref = (F.conv1d(F.leaky_relu(x.cpu(), 0.1).double(), w.double(), bias.cpu().double(), padding=pad, dilation=dil)
+           + res.cpu().double())
+    lim = 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.isfinite(two).all()
+    assert (two.cpu().double() - ref).abs().max().item() <= lim
+    assert (one.cpu().double() - ref).abs().max().item() <= lim
+    assert torch.equal(two, three)
+    assert not torch.equal(one, two)                   # the shares really ran (another summation order)
+    ws = native.workspace(DEV)
+    assert int(ws[:native.WS_COUNTER_BYTES // 4].view(torch.int32).abs().max()) == 0
+
+
 def test_split_channel_loop_workspace_contract():
     B, cin, cout, k, L = 1, 256, 256, 7, 2064
     x = _rand(B, cin, L, seed=311).to(DEV)

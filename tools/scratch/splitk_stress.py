@@ -4,6 +4,7 @@ import torch.nn.functional as F
 from vits_amd import native, packing
 from vits_amd.engine import choose_tile
 DEV = "cuda:0"
+SLICED = len(sys.argv) > 1 and sys.argv[1] == "sliced"      # the sliced-fp32 kernel instead of the fp32 one
 g = torch.Generator().manual_seed(5)
 bad = 0
 for it, (cin, cout, k, dil, B, L) in enumerate([(256, 256, 3, 1, 1, 2064), (256, 256, 11, 5, 1, 2064), (192, 384, 5, 1, 1, 258),
@@ -11,7 +12,8 @@ for it, (cin, cout, k, dil, B, L) in enumerate([(256, 256, 3, 1, 1, 2064), (256,
     x = torch.randn(B, cin, L, generator=g).to(DEV)
     w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
     tile = choose_tile(cout); ti = native.tile_info(tile)
-    wp = packing.pack_conv_weight(w, ti.ck, ti.rows_per_block).to(DEV)
+    wp = (packing.pack_conv_weight_split(w.to(DEV), ti.ck_split, ti.rows_per_block) if SLICED
+          else packing.pack_conv_weight(w, ti.ck, ti.rows_per_block).to(DEV))
     pad = (k - 1) * dil // 2
     def run(split, out):
         native.SPLIT_SMALL_LAUNCHES = split

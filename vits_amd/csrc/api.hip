@@ -198,7 +198,7 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     static const int xcd_env = diag_env("VK_XCD_MAP", -1);
     d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : !split);
     // A launch too small for 256 CUs splits its channel loop over several workgroups per output
-    // tile (fp32 kernel only): as many as bring it to about four workgroups per CU, at least two
+    // tile (fp32 and sliced-fp32 kernels): as many as bring it to about four workgroups per CU, at least two
     // chunks each, at most 8 (one utterance of 3 s, decoder: 2.07 ms at two per CU, 1.96 ms at four).
     // (Diagnostic build: VK_SPLITK_BELOW / VK_SPLITK_TARGET move the two thresholds.)  The partial accumulators and arrival counters live in scratch memory.
     d->ksplit = 1;
@@ -206,10 +206,14 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     *ws_need = 0;
     const int64_t wgs = (int64_t)d->n_tiles * d->n_rowblk * a->batch;
     static const int sk_below = diag_env("VK_SPLITK_BELOW", 512), sk_target = diag_env("VK_SPLITK_TARGET", 1024);
-    if (!bf16 && wgs < sk_below && d->nchunk >= 4 && (query || ws != nullptr)) {
-        int k = (int)(sk_target / wgs);
+    // (the sliced-fp32 kernel has thresholds of its own: VK_SPLITK_BELOW_S / VK_SPLITK_TARGET_S)
+    static const int sks_below = diag_env("VK_SPLITK_BELOW_S", 128), sks_target = diag_env("VK_SPLITK_TARGET_S", 256);
+    if ((!bf16 || split) && wgs < (split ? sks_below : sk_below) && d->nchunk >= 4 && (query || ws != nullptr)) {
+        int k = (int)((split ? sks_target : sk_target) / wgs);
         if (k > d->nchunk / 2) k = d->nchunk / 2;
         if (k > 8) k = 8;
+        if (split)                                   // the sliced-fp32 kernel's pipeline wants equal shares
+            while (k > 1 && d->nchunk % k) --k;
         if (k > 1) {
             *ws_need = VK_WS_COUNTER_BYTES + wgs * k * (int64_t)rows_blk * TN * 4;
             if (!query) {

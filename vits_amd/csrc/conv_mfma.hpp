@@ -60,7 +60,7 @@ struct ConvDev {
                         // from HBM once per XCD instead of once per row block
     int dbg;            // diagnostic build only (VK_DEBUG_SKIP): 1 = no epilogue, 2 = no MFMA loop,
                         // 4 = stage only the first chunk, 8 = barrier only on the first chunk
-    // Split of the channel loop (fp32 kernel only; 1 elsewhere).  With ksplit > 1, blockIdx.y
+    // Split of the channel loop (fp32 and sliced-fp32 kernels; 1 elsewhere).  With ksplit > 1, blockIdx.y
     // enumerates (split, row block); workgroup `split` runs chunks [split * nchunk / ksplit,
     // (split + 1) * nchunk / ksplit) and leaves its accumulators in `ws`; the last workgroup of an
     // output tile to arrive adds the partials in split order and runs the epilogue.
@@ -541,6 +541,64 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& d, f32x16 (&acc)[A_
     }
 }
 
+// Split channel loop, end of a workgroup's share: partial accumulators go to the workspace in
+// register order (a wave's register is 256 contiguous bytes); the workgroup that finds the tile's
+// counter at ksplit - 1 is the last, adds the partials in split order (its own included, so the
+// sum does not depend on who arrives last), clears the counter for the next launch and returns
+// true: it runs the epilogue.  The others return false.
+// The partials travel as device-scope accesses (written through to memory, read past the
+// caches) and a workgroup counts itself in only once its own stores have completed, so no
+// cache-wide write-back or invalidate is needed: a device-scope fence costs a small launch
+// about 40 us on the 8-XCD part, more than the split saves.
+// `arrived`: one LDS word nobody else uses at this point; every wave of the workgroup calls this.
+template <int A_REP, int B_REP, int NW>
+__device__ __forceinline__ bool vk_splitk_exchange(const ConvDev& d, f32x16 (&acc)[A_REP][B_REP], int b, int tile,
+                                                   int rowblk, int split, int w, int lane, unsigned* arrived)
+{
+    constexpr int PER_WAVE = A_REP * B_REP * 16 * 64;
+    const int tile_id = (b * d.n_tiles + tile) * d.n_rowblk + rowblk;
+    unsigned* counter = reinterpret_cast<unsigned*>(d.ws) + tile_id;
+    unsigned* part = reinterpret_cast<unsigned*>(d.ws) + VK_WS_COUNTER_BYTES / 4
+                   + ((size_t)tile_id * d.ksplit * NW + w) * PER_WAVE + lane;
+    unsigned* mine = part + (size_t)split * NW * PER_WAVE;
+#pragma unroll
+    for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+        for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[m][n][r];       // (a bit_cast straight from the vector element stores element 0)
+                __hip_atomic_store(mine + ((m * B_REP + n) * 16 + r) * 64, __builtin_bit_cast(unsigned, v),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    // this wave's write-through stores have completed (a workgroup-scope fence does not wait for them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // ... every wave's (and every wave is done with the staged tiles)
+    if (threadIdx.x == 0)
+        *arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*arrived != (unsigned)(d.ksplit - 1)) return false;
+#pragma unroll
+    for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+        for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    for (int sp = 0; sp < d.ksplit; ++sp) {
+        const unsigned* src = part + (size_t)sp * NW * PER_WAVE;
+#pragma unroll
+        for (int m = 0; m < A_REP; ++m)
+#pragma unroll
+            for (int n = 0; n < B_REP; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[m][n][r] += __builtin_bit_cast(float, __hip_atomic_load(src + ((m * B_REP + n) * 16 + r) * 64,
+                                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT, bool VEC>
 __global__ void __launch_bounds__(64 * WM * WN, (EPI == VK_EPI_SAMPLE) ? 2 : ((WM == 1 && WN == 4) ? 3 : 4))   // second figure: waves per SIMD the register budget must allow
 conv_mfma_kernel(const ConvDev d)
@@ -721,57 +779,8 @@ conv_mfma_kernel(const ConvDev d)
         d.stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 4] = boundary_ticks;
     if (kDiag && (d.dbg & 1) && acc[0][0][0] != 12345.678f) return;
 
-    if (d.ksplit > 1) {
-        // Split channel loop: partial accumulators go to the workspace in register order (a wave's
-        // register is 256 contiguous bytes); the workgroup that finds the tile's counter at
-        // ksplit - 1 is the last, adds the partials in split order (its own included, so the sum
-        // does not depend on who arrives last), clears the counter for the next launch and goes on.
-        // The partials travel as device-scope accesses (written through to memory, read past the
-        // caches) and a workgroup counts itself in only once its own stores have completed, so no
-        // cache-wide write-back or invalidate is needed: a device-scope fence costs this launch
-        // about 40 us on the 8-XCD part, more than the split saves.
-        constexpr int PER_WAVE = A_REP * B_REP * 16 * 64;
-        const int tile_id = (b * d.n_tiles + tile) * d.n_rowblk + rowblk;
-        unsigned* counter = reinterpret_cast<unsigned*>(d.ws) + tile_id;
-        unsigned* part = reinterpret_cast<unsigned*>(d.ws) + VK_WS_COUNTER_BYTES / 4
-                       + ((size_t)tile_id * d.ksplit * NW + w) * PER_WAVE + lane;
-        unsigned* mine = part + (size_t)split * NW * PER_WAVE;
-#pragma unroll
-        for (int m = 0; m < A_REP; ++m)
-#pragma unroll
-            for (int n = 0; n < B_REP; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[m][n][r];       // (a bit_cast straight from the vector element stores element 0)
-                    __hip_atomic_store(mine + ((m * B_REP + n) * 16 + r) * 64, __builtin_bit_cast(unsigned, v),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-        // this wave's write-through stores have completed (a workgroup-scope fence does not wait for them)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // ... every wave's (and every wave is done with the staged tiles)
-        unsigned* arrived = reinterpret_cast<unsigned*>(lds);
-        if (threadIdx.x == 0)
-            *arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*arrived != (unsigned)(d.ksplit - 1)) return;
-#pragma unroll
-        for (int m = 0; m < A_REP; ++m)
-#pragma unroll
-            for (int n = 0; n < B_REP; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-        for (int sp = 0; sp < d.ksplit; ++sp) {
-            const unsigned* src = part + (size_t)sp * NW * PER_WAVE;
-#pragma unroll
-            for (int m = 0; m < A_REP; ++m)
-#pragma unroll
-                for (int n = 0; n < B_REP; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[m][n][r] += __builtin_bit_cast(float, __hip_atomic_load(src + ((m * B_REP + n) * 16 + r) * 64,
-                                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (d.ksplit > 1 &&
+        !vk_splitk_exchange<A_REP, B_REP, NW>(d, acc, b, tile, rowblk, split, w, lane, reinterpret_cast<unsigned*>(lds)))
+        return;
     conv_epilogue<A_REP, B_REP, EPI>(d, acc, b, t0, mt0, wn, half, l31);
 }

@@ -60,7 +60,7 @@ __device__ __forceinline__ void vk_static_for(F&& f)
 
 // Position of a pipeline stage in the workgroup's run: which job, which chunk of it.
 struct SplitCursor {
-    int b, tile, rowblk, chunk;
+    int b, tile, split, rowblk, chunk;      // split: which share of the channel chunks (launches that split them)
 };
 
 // vector instructions of the cut scheduled behind each matrix instruction of a covering tap
@@ -137,7 +137,8 @@ struct SplitStager {
 };
 
 // Dynamic LDS of a launch: two staging buffers and the dump slots of units that do not exist.
-constexpr size_t vk_split_lds_bytes(int tn, int ck) { return (size_t)2 * (tn + 64) * (3 * ck * 2 + 16) + 64 * 16 + 4 * ck; }
+// (and one word for the arrival count of a split channel loop)
+constexpr size_t vk_split_lds_bytes(int tn, int ck) { return (size_t)2 * (tn + 64) * (3 * ck * 2 + 16) + 64 * 16 + 4 * ck + 16; }
 
 template <int A_REP, int B_REP, int WM, int WN, int CK, int EPI, bool ACT>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
@@ -169,23 +170,33 @@ conv_split_kernel(const ConvDev d)
     const int half = lane >> 5;
     const int l31  = lane & 31;
 
-    // this workgroup's run of jobs; job = (batch item, time tile, row block), row block fastest,
-    // so that the row blocks of a time tile, which stage the same x tile, follow each other
-    const int per = d.n_tiles * d.n_rowblk;
+    // this workgroup's run of jobs; job = (batch item, time tile, share of the channel chunks, row
+    // block), row block fastest, so that the row blocks of a time tile, which stage the same x
+    // tile, follow each other.  A launch too small for the GPU splits its channel chunks into
+    // ksplit equal shares (the host picks a divisor of nchunk); a share's partial sums meet the
+    // others' in scratch memory (vk_splitk_exchange).
+    const int cpj = d.nchunk / d.ksplit;            // chunks per job
+    const int per_tile = d.ksplit * d.n_rowblk;
+    const int per = d.n_tiles * per_tile;
     const int64_t total = (int64_t)per * p.batch;
     const int job0 = (int)(total * blockIdx.x / gridDim.x);
     const int njobs = (int)(total * (blockIdx.x + 1) / gridDim.x) - job0;
     if (njobs <= 0) return;
-    const int items = njobs * d.nchunk;
+    const int items = njobs * cpj;
 
     auto advance = [&](SplitCursor& c) {
-        if (++c.chunk < d.nchunk) return;
-        c.chunk = 0;
-        if (++c.rowblk < d.n_rowblk) return;
-        c.rowblk = 0;
-        if (++c.tile < d.n_tiles) return;
-        c.tile = 0;
-        ++c.b;
+        if (++c.chunk < (c.split + 1) * cpj) return;
+        if (++c.rowblk == d.n_rowblk) {
+            c.rowblk = 0;
+            if (++c.split == d.ksplit) {
+                c.split = 0;
+                if (++c.tile == d.n_tiles) {
+                    c.tile = 0;
+                    ++c.b;
+                }
+            }
+        }
+        c.chunk = c.split * cpj;
     };
 
     vk_stamp(d, 0);
@@ -193,9 +204,14 @@ conv_split_kernel(const ConvDev d)
     stg.init(d, lane, w);
     SplitCursor cur;                      // the item being multiplied
     cur.b = job0 / per;
-    cur.tile = (job0 - cur.b * per) / d.n_rowblk;
-    cur.rowblk = job0 - cur.b * per - cur.tile * d.n_rowblk;
-    cur.chunk = 0;
+    {
+        const int in_item = job0 - cur.b * per;
+        cur.tile = in_item / per_tile;
+        const int in_tile = in_item - cur.tile * per_tile;
+        cur.split = in_tile / d.n_rowblk;
+        cur.rowblk = in_tile - cur.split * d.n_rowblk;
+    }
+    cur.chunk = cur.split * cpj;
     SplitCursor cvt = cur;                // the item being cut into slices (one ahead)
     SplitCursor ldc = cur;                // the item whose loads are issued next (three ahead)
     int to_issue = items;
@@ -210,9 +226,10 @@ conv_split_kernel(const ConvDev d)
     };
 
     // ---- weights: per (tap, k-step) three 16-byte fragments per lane: hi, mid, lo ----
-    auto wbase = [&](int rowblk, int m) {
-        const int mt = (rowblk * WM + wm) * A_REP + m;
-        return reinterpret_cast<const bf16x8*>(p.w) + ((int64_t)mt * d.groups_per_mt) * 64 + lane;
+    auto wbase = [&](const SplitCursor& c, int m) {     // where job c's weight stream starts
+        const int mt = (c.rowblk * WM + wm) * A_REP + m;
+        return reinterpret_cast<const bf16x8*>(p.w)
+             + ((int64_t)mt * d.groups_per_mt + (int64_t)c.split * cpj * p.taps * (3 * KS)) * 64 + lane;
     };
 
     f32x16 acc[A_REP][B_REP];
@@ -220,7 +237,8 @@ conv_split_kernel(const ConvDev d)
         // accumulators start at the bias of their row: register r of a lane is row
         // (r & 3) + 8 * (r >> 2) + 4 * half of its 32-row tile
         const int mt0 = (c.rowblk * WM + wm) * A_REP;
-        const float* biasb = p.bias ? p.bias + (int64_t)c.b * p.bias_bstride : nullptr;
+        // (of a split channel loop only the first share carries the bias)
+        const float* biasb = (p.bias && c.split == 0) ? p.bias + (int64_t)c.b * p.bias_bstride : nullptr;
         const int rows_total_b = PAIR ? 2 * p.hidden : p.c_out;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) {
@@ -257,7 +275,7 @@ conv_split_kernel(const ConvDev d)
     const bf16x8* aptr[A_REP];
     bf16x8 a[KS][3][A_REP];
 #pragma unroll
-    for (int m = 0; m < A_REP; ++m) aptr[m] = wbase(cur.rowblk, m);
+    for (int m = 0; m < A_REP; ++m) aptr[m] = wbase(cur, m);
 #pragma unroll
     for (int k = 0; k < KS; ++k)
 #pragma unroll
@@ -286,7 +304,7 @@ conv_split_kernel(const ConvDev d)
         // transposed conv: row tiles of the upper phases read the staged tile one column later
         const int shift = (EPI == VK_EPI_UPSAMPLE) ? vk_ups_shift(p, mt0) : 0;
         const char* base = lds8 + SET * BUF + (wn * TNW + l31 + shift) * PITCH + half * 16;
-        const bool last_chunk = cur.chunk + 1 == d.nchunk;
+        const bool last_chunk = cur.chunk + 1 == (cur.split + 1) * cpj;
         SplitCursor nxt = cur;            // the job after this one (where its weight stream starts)
         if (last_chunk) advance(nxt);
 
@@ -308,7 +326,7 @@ conv_split_kernel(const ConvDev d)
             const bf16x8* an[A_REP];
 #pragma unroll
             for (int m = 0; m < A_REP; ++m)
-                an[m] = (last_tap && last_chunk) ? wbase(nxt.rowblk, m) : aptr[m] + 64 * 3 * KS;
+                an[m] = (last_tap && last_chunk) ? wbase(nxt, m) : aptr[m] + 64 * 3 * KS;
             bf16x8 a_nxt[KS][3][A_REP];
 #pragma unroll
             for (int k = 0; k < KS; ++k)
@@ -388,7 +406,11 @@ conv_split_kernel(const ConvDev d)
         } else
         __syncthreads();
         if (last_chunk) {
-            conv_epilogue<A_REP, B_REP, EPI>(d, acc, cur.b, cur.tile * TN, mt0, wn, half, l31);
+            // (the arrival word sits behind the staging buffers and the dump slots)
+            const bool finish = d.ksplit == 1 ||
+                vk_splitk_exchange<A_REP, B_REP, NW>(d, acc, cur.b, cur.tile, cur.rowblk, cur.split, w, lane,
+                                                    reinterpret_cast<unsigned*>(lds8 + 2 * BUF + 64 * 16 + 4 * CK));
+            if (finish) conv_epilogue<A_REP, B_REP, EPI>(d, acc, cur.b, cur.tile * TN, mt0, wn, half, l31);
             if (more) init_acc(nxt);
         }
         advance(cur);
@@ -439,7 +461,7 @@ inline int vk_resident_workgroups(K kernel, int threads, size_t lds, std::atomic
         static std::atomic<unsigned long long> lds_raised{0};   /* bit d: limit raised on device d */\
         if (hipError_t e = vk_allow_lds(k, lds, lds_raised); e != hipSuccess) return (int)e;     \
         static std::atomic<int> resident{0};                                                     \
-        const int64_t jobs = (int64_t)d.n_tiles * d.n_rowblk * d.a.batch;                        \
+        const int64_t jobs = (int64_t)d.n_tiles * d.n_rowblk * d.a.batch * d.ksplit;             \
         const int slots = vk_resident_workgroups(k, 64 * G.wm * G.wn, lds, resident);            \
         const dim3 pgrid((unsigned)(jobs < slots ? jobs : slots), 1, 1);                         \
         hipLaunchKernelGGL(k, pgrid, dim3(64 * G.wm * G.wn), lds, s, d);                         \

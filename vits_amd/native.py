@@ -395,7 +395,7 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     blocks = -(-x.shape[2] // ti.time_tile) * -(-rows_all // ti.rows_per_block) * x.shape[0]
     a.narrow = int(precision == PREC_F32 and blocks < NARROW_BELOW_BLOCKS)
     L = lib()
-    if precision == PREC_F32 and blocks < 512 and SPLIT_SMALL_LAUNCHES and not static_scratch:
+    if precision in (PREC_F32, PREC_F32_SPLIT) and blocks < 512 and SPLIT_SMALL_LAUNCHES and not static_scratch:
         # far too few workgroups for 256 CUs: with scratch the library splits the channel loop
         # (it decides itself whether to; under capture only launches that will split ask for the
         # capture workspace, so a foreign capture without one keeps working for the others)
