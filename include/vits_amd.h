@@ -119,7 +119,7 @@ typedef struct {
     float   navg;         /* VK_EPI_RESID_AVG divisor */
     int32_t precision;    /* VK_PREC_* (selects the packed weight format too) */
     int32_t narrow;       /* 1: half the family's time tile (twice the workgroups, same packed weights);
-                             for launches too small to fill the GPU.  VK_PREC_F32 only, ignored otherwise */
+                             for launches too small to fill the GPU.  VK_PREC_F32 and VK_PREC_BF16; ignored otherwise */
     /* Scratch for launches too small to fill the GPU (VK_PREC_F32 and VK_PREC_F32_SPLIT): with it, such a launch
      * splits the channel loop over up to 8 workgroups per output tile; each writes its partial
      * accumulators here and the last one to arrive adds them in a fixed order and runs the

@@ -85,7 +85,7 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     if (a->precision < VK_PREC_F32 || a->precision > VK_PREC_F32_SPLIT) return vk_fail(VK_E_ARG, "vk_conv1d: bad precision id");
     const bool split = a->precision == VK_PREC_F32_SPLIT;
     const bool bf16 = a->precision == VK_PREC_BF16 || split;      // bf16 matrix instructions, channel-minor LDS tile
-    const bool narrow = a->narrow && !bf16;
+    const bool narrow = a->narrow && !split;
     const TileGeom& G = split ? kSplitTiles[a->tile] : (narrow ? kTilesNarrow[a->tile] : kTiles[a->tile]);
     const int TN = 32 * G.b_rep * G.wn;
     const bool ups = a->epilogue == VK_EPI_UPSAMPLE;
@@ -321,6 +321,13 @@ static int conv1d_launch(const vk_conv_args* a, const ConvDev& d, dim3 grid, siz
         case VK_TILE_M64:  e = vk_launch_split_tile1(a->epilogue, act, d, grid, lds, s); break;
         case VK_TILE_M32:  e = vk_launch_split_tile2(a->epilogue, act, d, grid, lds, s); break;
         case VK_TILE_PAIR: e = vk_launch_split_tile3(a->epilogue, act, d, grid, lds, s); break;
+        }
+    } else if (a->precision == VK_PREC_BF16 && a->narrow) {
+        switch (a->tile) {
+        case VK_TILE_M128: e = vk_launch_bf16_tile0n(a->epilogue, act, d, grid, lds, s); break;
+        case VK_TILE_M64:  e = vk_launch_bf16_tile1n(a->epilogue, act, d, grid, lds, s); break;
+        case VK_TILE_M32:  e = vk_launch_bf16_tile2n(a->epilogue, act, d, grid, lds, s); break;
+        case VK_TILE_PAIR: e = vk_launch_bf16_tile3n(a->epilogue, act, d, grid, lds, s); break;
         }
     } else if (a->precision == VK_PREC_BF16) {
         switch (a->tile) {

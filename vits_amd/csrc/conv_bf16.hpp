@@ -302,3 +302,7 @@ int vk_launch_bf16_tile0(int epi, int act, const ConvDev& d, dim3 grid, size_t l
 int vk_launch_bf16_tile1(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
 int vk_launch_bf16_tile2(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
 int vk_launch_bf16_tile3(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_bf16_tile0n(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_bf16_tile1n(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_bf16_tile2n(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_bf16_tile3n(int epi, int act, const ConvDev& d, dim3 grid, size_t lds, hipStream_t s);

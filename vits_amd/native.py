@@ -393,7 +393,7 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     rows_all = c_out * up_stride if epilogue == EPI_UPSAMPLE else (2 * hidden if epilogue in (EPI_GATE, EPI_SAMPLE) else c_out)
     ti = tile_info(tile)
     blocks = -(-x.shape[2] // ti.time_tile) * -(-rows_all // ti.rows_per_block) * x.shape[0]
-    a.narrow = int(precision == PREC_F32 and blocks < NARROW_BELOW_BLOCKS)
+    a.narrow = int(precision in (PREC_F32, PREC_BF16) and blocks < NARROW_BELOW_BLOCKS)
     L = lib()
     if precision in (PREC_F32, PREC_F32_SPLIT) and blocks < 512 and SPLIT_SMALL_LAUNCHES and not static_scratch:
         # far too few workgroups for 256 CUs: with scratch the library splits the channel loop
