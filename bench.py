@@ -188,7 +188,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ------------------------------------------------------------------ corpus (BASELINE config 5)
+    # ------------------------------------------------------------------ corpus (4096 length-bucketed utterances, sharded)
     def corpus_pass(steps: int, warmup: int):
         """The 4096-utterance length-bucketed corpus, sharded over the ranks by bucket (strong
         scaling): ``steps`` timed passes over this rank's shard, three of its utterances checked

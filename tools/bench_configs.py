@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the BASELINE.json configurations other than the headline one (needs a GPU):
+"""Times the benchmark configurations other than the headline one (needs a GPU):
   1  text_to_speech, one ~3 s sentence: CPU oracle path vs the drop-in generator on the GPU
   2  decoder only, B=1, T=862 and T=258 (latency), eager and replayed as one HIP graph
   4  voice conversion (posterior encoder -> flow fwd -> flow rev -> decoder), B=64, T=862, in every
