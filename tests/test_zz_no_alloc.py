@@ -20,7 +20,7 @@ def _rand(*shape, seed):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
 
 
-def _both_entries(cin, cout, k, dil, B, L, seed):
+def _both_entries(cin, cout, k, dil, B, L, seed, sliced=False):
     x = _rand(B, cin, L, seed=seed).to(DEV)
     w = _rand(cout, cin, k, seed=seed + 1) / (cin * k) ** 0.5
     bias = _rand(cout, seed=seed + 2).to(DEV)
@@ -28,7 +28,8 @@ def _both_entries(cin, cout, k, dil, B, L, seed):
     pad = (k - 1) * dil // 2
     tile = choose_tile(cout)
     ti = native.tile_info(tile)
-    wp = packing.pack_conv_weight(w, ti.ck, ti.rows_per_block).to(DEV)
+    wp = (packing.pack_conv_weight_split(w.to(DEV), ti.ck_split, ti.rows_per_block) if sliced
+          else packing.pack_conv_weight(w, ti.ck, ti.rows_per_block).to(DEV))
     outs = []
     for static in (False, True):
         out = torch.full((B, cout, L), float("nan"), device=DEV)
@@ -61,6 +62,16 @@ def test_static_scratch_entry_matches_the_workspace_entry():
                   epilogue=native.EPI_STORE, static_scratch=True)
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] == free0 and torch.cuda.memory_allocated() == alloc0
+
+
+def test_static_scratch_entry_with_the_sliced_fp32_kernel():
+    """The sliced-fp32 kernel shares out its channel chunks through the same scratch: the static
+    entry and the workspace entry agree bit for bit there too, on two calls in a row."""
+    for (cin, cout, k, dil, B, L), seed in (((256, 256, 7, 1, 1, 2064), 461), ((192, 384, 5, 1, 1, 237), 471)):
+        with_ws, static, ref = _both_entries(cin, cout, k, dil, B, L, seed, sliced=True)
+        assert torch.isfinite(static).all()
+        assert torch.equal(with_ws, static), (with_ws - static).abs().max().item()
+        assert (static.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_static_scratch_entry_without_a_split_and_beyond_its_size():
