@@ -180,7 +180,7 @@ def main():
     tol = BF16_TOL if args.precision == "bf16" else PARITY_TOL
 
     def hot_path(z, mask, speakers):
-        return gen.flow_reverse_decode(z, mask, gen.embed_speaker(speakers))
+        return gen.flow_reverse_decode(z, mask, gen.speaker_ref(speakers))     # speaker conditioning: table rows
 
     def fence():
         torch.cuda.synchronize(dev)

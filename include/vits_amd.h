@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 7
+#define VK_ABI_VERSION 8
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -128,6 +128,15 @@ typedef struct {
      * launch leaves them zero again.  Launches that may overlap in time (other streams) need
      * workspaces of their own. */
     void*   workspace;    int64_t workspace_bytes;
+    /* Per-speaker bias table (decoder.py:91,112 `cond`; wn.py:41-42,66 `condition_layer` applied to
+     * an embedding that is a row of vits_generator.py:88-91's table): with bias_index, batch item b
+     * takes bias row bias_index[b] (clamped to [0, bias_rows)) of a [bias_rows, *] table whose row
+     * stride is bias_bstride, instead of row b.  NULL: row b. */
+    const int64_t* bias_index;  int32_t bias_rows;
+    /* x is read as x[b, c, t] * in_mask[b, t] ([B, L] floats; vits_generator.py:186 `z * spec_mask`
+     * in front of the decoder's first convolution).  NULL: x as it is.  Not with 16-byte staging
+     * of the fp32 kernel's activated inputs (the launch falls back to 4-byte staging). */
+    const float* in_mask;
 } vk_conv_args;
 
 #define VK_WS_COUNTER_BYTES 65536
@@ -210,6 +219,7 @@ typedef struct {
     const float* mask;                                                 /* [B, L] */
     int32_t batch, hidden, length, taps, dilation;
     int32_t first, last;                                               /* first: skip starts at zero */
+    const int64_t* cond_index;  int32_t cond_rows;                     /* as vk_conv_args.bias_index: row of a per-speaker table */
 } vk_wn_args;
 
 int vk_wn_query(int hidden, vk_tile_info* info);
@@ -295,6 +305,8 @@ typedef struct {
     int32_t num_bins;      /* coupling: 10 */
     float   tail_bound;    /* coupling: identity outside [-tail_bound, tail_bound] */
     float   in_scale;      /* coupling: x is read as in_scale * x (noise scale of the first flow) */
+    const int64_t* add_index;  int32_t add_rows;   /* condition: add_vec row of item b is add_index[b] (clamped) of an
+                                                      [add_rows, C] per-speaker table; NULL: row b */
 } vk_dds_args;
 
 int64_t vk_dds_workspace_bytes(int batch, int length);

@@ -129,16 +129,16 @@ def test_front_graph_draws_fresh_duration_noise():
     torch.manual_seed(7)
     draws = []
     for _ in range(3):
-        _, _, _, w_ceil, _ = gen._token_stage_graphed(ids, lens, spk, None, 3, 0.8)
+        _, _, _, w_ceil = gen._token_stage_graphed(ids, lens, spk, None, 3, 0.8)
         draws.append(w_ceil.clone().cpu())
     assert len(gen._front_graphs) == 1
     assert not (torch.equal(draws[0], draws[1]) and torch.equal(draws[1], draws[2]))
     # the draw comes from the CPU generator exactly as in the eager path: same seed, same durations
     torch.manual_seed(11)
-    _, _, _, w_graph, _ = gen._token_stage_graphed(ids, lens, spk, None, 3, 0.8)
+    _, _, _, w_graph = gen._token_stage_graphed(ids, lens, spk, None, 3, 0.8)
     w_graph = w_graph.clone().cpu()
     torch.manual_seed(11)
-    _, _, _, w_eager, _ = gen._token_stage(ids, lens, spk, None, 3, 0.8)
+    _, _, _, w_eager = gen._token_stage(ids, lens, spk, None, 3, 0.8)
     assert torch.equal(w_graph, w_eager.cpu())
     wav = gen.text_to_speech(ids, lens, spk, length_scale=3)
     assert torch.isfinite(wav).all() and wav.shape[2] % 256 == 0

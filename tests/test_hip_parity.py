@@ -243,7 +243,7 @@ def test_front_half_graph_replay_matches_eager():
     eager = [tuple(t.clone() for t in gen._token_stage(ids, lens, spk, nw, 3, 0.8)) for ids, spk, nw in cases]
     for (ids, spk, nw), ref in zip(cases, eager):
         got = gen._token_stage_graphed(ids, lens, spk, nw, 3, 0.8)
-        for name, a, b in zip(("m_p", "logs_p", "text_mask", "w_ceil", "g"), got, ref):
+        for name, a, b in zip(("m_p", "logs_p", "text_mask", "w_ceil"), got, ref):
             assert a.shape == b.shape, name
             assert torch.equal(a, b), name
     assert len(gen._front_graphs) == 1

@@ -194,7 +194,7 @@ def test_frame_prior_with_and_without_the_expand_kernel(gens):
         b = gpu.frame_prior(ids, lens, spk, length_scale=3, noise_w=nw)
     finally:
         del gpu.use_expand_kernel
-    for x, y in zip(a, b):
+    for x, y in zip(a[:3], b[:3]):                  # (the fourth entry names the speakers)
         assert x.shape == y.shape and torch.equal(x, y)
 
 

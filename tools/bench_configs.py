@@ -67,15 +67,15 @@ def run(dev, seed: int = 999, vc_batch: int = 64, cpu_reps: int = 2):
     out["config1_text_to_speech"] = c1
 
     # ---- config 2: decoder only, one utterance
-    gd = gen.embed_speaker(torch.tensor([9], device=dev))
+    gd = gen.speaker_ref(torch.tensor([9], device=dev))       # conditioning as a row of the per-speaker table
     c2 = {}
     for prec in ("fp32", "fp32-split"):
         engine.set_precision(prec)
         for T in (862, 258):
             z = synth.latent(seed, "cfg2.z", 1, T).to(dev)
             dt, _ = _timed(lambda: gen.decoder(z, gd), 20)
-            graphed = GraphedCall(gen.decoder, z, gd)
-            dtg, _ = _timed(lambda: graphed(z, gd), 30)
+            graphed = GraphedCall(lambda zz: gen.decoder(zz, gd), z)
+            dtg, _ = _timed(lambda: graphed(z), 30)
             c2[f"{prec}_T{T}"] = {"ms": 1e3 * dt, "graph_ms": 1e3 * dtg, "value": T * HOP / SAMPLE_RATE / min(dt, dtg)}
     out["config2_decoder_b1"] = c2
 

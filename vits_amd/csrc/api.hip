@@ -144,7 +144,8 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     d->nchunk = (a->c_in + ck - 1) / ck;
     // 16-byte staging when every row of x starts 16-byte aligned and the length is a multiple of 4
     static const int no_vec = diag_env("VK_NO_VEC", 0);
-    *vec = !no_vec && !bf16 && a->act_in &&
+    if (a->bias_index && (!a->bias || a->bias_rows <= 0)) return vk_fail(VK_E_ARG, "vk_conv1d: bias_index without a bias table");
+    *vec = !no_vec && !bf16 && a->act_in && !a->in_mask &&
            ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) && (a->length % 4 == 0) &&
            (a->epilogue == VK_EPI_STORE || a->epilogue == VK_EPI_RESID || a->epilogue == VK_EPI_RESID_ACC ||
             a->epilogue == VK_EPI_RESID_AVG || a->epilogue == VK_EPI_UPSAMPLE) && a->tile != VK_TILE_PAIR;
@@ -484,6 +485,7 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
     if (!a->x || !a->w_in || !a->cond || !a->w_rs || !a->x_out || !a->skip || !a->mask)
         return vk_fail(VK_E_ARG, "vk_wn_layer: null pointer");
     if (a->hidden != 32 * VK_WN_WAVES) return vk_fail(VK_E_UNSUPPORTED, "vk_wn_layer: built for hidden = 192");
+    if (a->cond_index && a->cond_rows <= 0) return vk_fail(VK_E_ARG, "vk_wn_layer: cond_index without cond_rows");
     if (a->batch <= 0 || a->batch > 65535 || a->length <= 0 || a->taps < 1 || a->dilation < 1)
         return vk_fail(VK_E_ARG, "vk_wn_layer: bad size");
     const int halo = (a->taps - 1) * a->dilation;
@@ -513,6 +515,7 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
     c.batch = a->batch; c.c_in = a->hidden; c.c_out = 2 * a->hidden; c.length = a->length;
     c.taps = a->taps; c.dilation = a->dilation; c.pad = halo / 2;
     c.first = a->first; c.hidden = a->hidden;
+    c.bias_index = a->cond_index; c.bias_rows = a->cond_rows;
     q.c.x_bytes = (unsigned)xb; q.c.out_bytes = (unsigned)ob; q.c.res_bytes = (unsigned)xb; q.c.out2_bytes = (unsigned)sb;
     q.c.nchunk = a->hidden / VK_WN_CK;
     static const int no_vec = diag_env("VK_NO_VEC", 0);

@@ -31,9 +31,10 @@ struct Bf16Stager {
     bool u_in[NI];          // this lane's column lies inside [0, L)
     bool u_on[NI];          // wave-uniform: the unit exists and its piece overlaps the staged width
     float st[NI][8];
+    float u_mk[NI];         // input mask of this lane's column (only read when the launch has one)
     __amdgpu_buffer_rsrc_t rx;
 
-    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane, int w)
+    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane, int w, int b = 0)
     {
         const int L = d.a.length;
         rx = vk_rsrc(xb, d.x_bytes);
@@ -48,6 +49,7 @@ struct Bf16Stager {
             u_voff[i] = 4 * (t < 0 ? 0 : (t >= L ? L - 1 : t));
             u_in[i] = (t >= 0) && (t < L);
             u_lds[i] = col * PITCH + cg * 16;
+            if (d.a.in_mask != nullptr) u_mk[i] = d.a.in_mask[(int64_t)b * L + (u_voff[i] >> 2)];     // wave-uniform branch
         }
     }
     __device__ __forceinline__ void issue(const ConvDev& d, int chunk)
@@ -75,6 +77,7 @@ struct Bf16Stager {
                     const int c = chunk * CK + u_cg[i] * 8 + c8;
                     float v0 = (u_in[i] && c < d.a.c_in) ? st[i][c8] : 0.0f;
                     float v1 = (u_in[i] && c + 1 < d.a.c_in) ? st[i][c8 + 1] : 0.0f;
+                    if (d.a.in_mask != nullptr) { v0 *= u_mk[i]; v1 *= u_mk[i]; }
                     if (ACT) { v0 = vk_lrelu(v0, d.a.in_slope); v1 = vk_lrelu(v1, d.a.in_slope); }
                     const f32x2 pr = {v0, v1};
                     const bf16x2 q = __builtin_convertvector(pr, bf16x2);
@@ -236,7 +239,7 @@ conv_bf16_kernel(const ConvDev d)
 
     const float* xb = p.x + (int64_t)b * p.x_bstride;
     Bf16Stager<NW, NJ, CK, PITCH, ACT> stg;
-    stg.init(d, xb, t0, lane, w);
+    stg.init(d, xb, t0, lane, w, b);
     stg.issue(d, 0);
 
     // ---- weight stream: one 16-byte fragment per lane per matrix instruction ----
@@ -251,7 +254,7 @@ conv_bf16_kernel(const ConvDev d)
     {
         // accumulators start at the bias of their row: register r of a lane is row
         // (r & 3) + 8 * (r >> 2) + 4 * half of its 32-row tile
-        const float* biasb = p.bias ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
+        const float* biasb = p.bias ? vk_bias_of(p, b) : nullptr;
         const int rows_total_b = PAIR ? 2 * p.hidden : p.c_out;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) {

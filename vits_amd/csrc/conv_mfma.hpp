@@ -102,6 +102,17 @@ __device__ __forceinline__ void vk_bst(float v, __amdgpu_buffer_rsrc_t r, int vo
 {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
 }
+// Bias vector of batch item b: row b of [B, *], or with a bias index (a per-speaker table) the
+// row that the item's index names, clamped into the table.
+__device__ __forceinline__ const float* vk_bias_of(const vk_conv_args& p, int b)
+{
+    long long row = b;
+    if (p.bias_index != nullptr) {
+        row = p.bias_index[b];
+        row = row < 0 ? 0 : (row >= p.bias_rows ? p.bias_rows - 1 : row);
+    }
+    return p.bias + row * p.bias_bstride;
+}
 // leaky-ReLU with 0 <= slope <= 1 is max(v, slope * v); one v_max_f32 without the compiler's
 // canonicalising pre-max (NaN in gives NaN out either way).
 __device__ __forceinline__ float vk_lrelu(float v, float slope)
@@ -119,9 +130,10 @@ struct ScalarStager {
     unsigned inrange;           // bit j: that column lies inside [0, L)
     bool last_col_ok;
     float st[RPW][NJ];
+    float mk[NJ];               // input mask of column j*64 + lane (only read when the launch has one)
     __amdgpu_buffer_rsrc_t rx;
 
-    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane)
+    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane, int b)
     {
         const int L = d.a.length;
         rx = vk_rsrc(xb, d.x_bytes);
@@ -133,6 +145,7 @@ struct ScalarStager {
             const int t = t0 - d.a.pad + col;
             toff[j] = 4 * (t < 0 ? 0 : (t >= L ? L - 1 : t));
             if (t >= 0 && t < L) inrange |= 1u << j;
+            if (d.a.in_mask != nullptr) mk[j] = d.a.in_mask[(int64_t)b * L + (toff[j] >> 2)];     // wave-uniform branch
         }
         last_col_ok = (lane + 64 * (NJ - 1)) < d.xw;          // only the last piece can overhang
     }
@@ -156,6 +169,7 @@ struct ScalarStager {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float v = (cok && ((inrange >> j) & 1u)) ? st[r][j] : 0.0f;
+                if (d.a.in_mask != nullptr) v *= mk[j];
                 if (ACT) v = vk_lrelu(v, d.a.in_slope);
                 if (j < NJ - 1 || last_col_ok) dst[64 * j] = v;
             }
@@ -174,7 +188,7 @@ struct VectorStager {
     float4 st[RPW][NJ4];
     __amdgpu_buffer_rsrc_t rx;
 
-    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane)
+    __device__ __forceinline__ void init(const ConvDev& d, const float* xb, int t0, int lane, int /*b*/)
     {
         const int L = d.a.length;
         const int ts = t0 - d.a.pad - d.col0;                   // multiple of 4
@@ -652,7 +666,7 @@ conv_mfma_kernel(const ConvDev d)
     using Stager = typename std::conditional<VEC, VectorStager<RPW, NJ4, NW, CK, ACT>,
                                                   ScalarStager<RPW, NJ, NW, CK, ACT>>::type;
     Stager stg;
-    stg.init(d, xb, t0, lane);
+    stg.init(d, xb, t0, lane, b);
     auto issue_loads = [&](int chunk) { stg.issue(d, chunk, w); };
     auto store_chunk = [&](int chunk, float* buf) { stg.store(d, chunk, buf, w, lane); };
     issue_loads(c_begin);    // first: the longest latency of the prologue; weights and bias follow it
@@ -678,7 +692,7 @@ conv_mfma_kernel(const ConvDev d)
         // accumulators start at the bias of their row: register r of a lane is row
         // (r & 3) + 8 * (r >> 2) + 4 * half of its 32-row tile
         // (of a split channel loop only the first share carries the bias)
-        const float* biasb = (p.bias && split == 0) ? p.bias + (int64_t)b * p.bias_bstride : nullptr;
+        const float* biasb = (p.bias && split == 0) ? vk_bias_of(p, b) : nullptr;
         const int rows_total_b = PAIR ? 2 * p.hidden : p.c_out;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) {

@@ -79,6 +79,7 @@ struct SplitStager {
     int  u_cg[NI];          // channel group (wave-uniform)
     bool u_on[NI];          // wave-uniform: the unit exists and its piece overlaps the staged width
     float st[2][NI][8];     // two items in flight; set and unit are compile-time indices after unrolling
+    float mk[2][NI];        // input mask of this lane's column of the item (only with an input mask)
 
     __device__ __forceinline__ void init(const ConvDev& d, int lane, int w)
     {
@@ -108,6 +109,7 @@ struct SplitStager {
             const int soff = (int)((ch < d.a.c_in ? ch : 0) * d.a.x_cstride * 4);
             st[SET][i][c8] = vk_bld(rx, voff, soff);
         }
+        if (d.a.in_mask != nullptr) mk[SET][i] = d.a.in_mask[(int64_t)c.b * L + (voff >> 2)];     // wave-uniform branch
     }
     // Straight-line code (no branch), so that it can be scheduled between the matrix
     // instructions of a tap.  A unit that does not exist cuts whatever its registers hold and
@@ -124,6 +126,7 @@ struct SplitStager {
             const int ch = c.chunk * CK + u_cg[i] * 8 + c8;
             float v0 = (in && ch < d.a.c_in) ? st[SET][i][c8] : 0.0f;
             float v1 = (in && ch + 1 < d.a.c_in) ? st[SET][i][c8 + 1] : 0.0f;
+            if (d.a.in_mask != nullptr) { v0 *= mk[SET][i]; v1 *= mk[SET][i]; }
             if (ACT) { v0 = vk_lrelu(v0, d.a.in_slope); v1 = vk_lrelu(v1, d.a.in_slope); }
             unsigned h, m, l;
             vk_split3_pair(v0, v1, h, m, l);
@@ -238,7 +241,7 @@ conv_split_kernel(const ConvDev d)
         // (r & 3) + 8 * (r >> 2) + 4 * half of its 32-row tile
         const int mt0 = (c.rowblk * WM + wm) * A_REP;
         // (of a split channel loop only the first share carries the bias)
-        const float* biasb = (p.bias && c.split == 0) ? p.bias + (int64_t)c.b * p.bias_bstride : nullptr;
+        const float* biasb = (p.bias && c.split == 0) ? vk_bias_of(p, c.b) : nullptr;
         const int rows_total_b = PAIR ? 2 * p.hidden : p.c_out;
 #pragma unroll
         for (int m = 0; m < A_REP; ++m) {

@@ -112,7 +112,7 @@ resblock_pair_kernel(const PairDev q)
     using Stager = typename std::conditional<VEC, VectorStager<RPW, NJ4, NW, CK, true>,
                                                   ScalarStager<RPW, NJ, NW, CK, true>>::type;
     Stager stg;
-    stg.init(d, xb, t0, lane);
+    stg.init(d, xb, t0, lane, b);
     stg.issue(d, 0, w);
 
     // ------------------------------ first convolution ------------------------------

@@ -295,7 +295,12 @@ dds_layer_kernel(LayerDev p)
         quarter_product<NC + 2>(wq, yb, part, r, q);
         weights_fetch(wq, pw_wt, r, q);
         __syncthreads();
-        const float add = a.pre_b[r] + (a.add_vec ? a.add_vec[(int64_t)b * DC + r] : 0.0f);
+        long long add_row = b;                  // row of the speaker vector: the item's own, or its row of a per-speaker table
+        if (a.add_index != nullptr) {
+            add_row = a.add_index[b];
+            add_row = add_row < 0 ? 0 : (add_row >= a.add_rows ? a.add_rows - 1 : add_row);
+        }
+        const float add = a.pre_b[r] + (a.add_vec ? a.add_vec[add_row * DC + r] : 0.0f);
         for (int col = q; col < NC + 2; col += NQ) xw[r * XP + col] = part_sum(part, r, col) + add;
     }
     __syncthreads();

@@ -108,7 +108,7 @@ wn_layer_kernel(const WnDev q)
     using Stager = typename std::conditional<VEC, VectorStager<RPW, NJ4, NWAVES, CK, false>,
                                                   ScalarStager<RPW, NJ, NWAVES, CK, false>>::type;
     Stager stg;
-    stg.init(d, xb, t0, lane);
+    stg.init(d, xb, t0, lane, b);
     stg.issue(d, 0, w);
 
     // ---------------- in-conv: row tiles 2w (tanh half) and 2w + 1 (sigmoid half) ----------------
@@ -124,7 +124,7 @@ wn_layer_kernel(const WnDev q)
 
     f32x16 acc[2][B_REP];
     {
-        const float* biasb = p.bias + (int64_t)b * p.bias_bstride;
+        const float* biasb = vk_bias_of(p, b);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             float bv[16];

@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 
 from ... import native, packing
-from ...engine import PackedConv, PlainConvParams, PlanCache, WeightNormConvParams, require_device
+from ...engine import PackedConv, PlainConvParams, PlanCache, SpeakerTables, WeightNormConvParams, require_device
 
 LRELU_SLOPE = 0.1
 
@@ -166,6 +166,7 @@ class DecoderPlan:
         self.pre = PackedConv(pre.effective_weight(), None, device)
         self.cond_w = dec.cond.weight.detach().to(device)[:, :, 0].contiguous()
         self.cond_b = (dec.cond.bias.detach() + pre.bias.detach()).to(device).contiguous()
+        self.speakers = SpeakerTables(self.cond_w, self.cond_b)     # cond(g) + conv1d_pre's bias, per utterance or per speaker
         self.ups = []
         for i, (s, k) in enumerate(zip(dec.deconv_strides, dec.deconv_kernel_sizes)):
             up = dec.ups[i]
@@ -285,21 +286,26 @@ class Decoder(nn.Module):
         main.wait_event(prev_done)
 
     @torch.no_grad()
-    def forward(self, z, speaker_id_embedded):
+    def forward(self, z, speaker_id_embedded, z_mask=None):
+        """``z_mask`` [B, 1, T] (not an argument of the reference): the decoder reads z * z_mask, the
+        product the reference's callers form before the call (vits_generator.py:186,196), taken
+        while the first convolution stages its input."""
         require_device(z, "Decoder.forward")
         dev = z.device
         plan = self._plans.get(dev)
-        z = z.to(torch.float32).contiguous()
+        if z.dtype != torch.float32 or z.stride(2) != 1:
+            z = z.to(torch.float32).contiguous()        # (a slice along time is read in place)
         B, _, T = z.shape
-        g2 = speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous()
         c0 = self.upsample_initial_channel
+        in_mask = None
+        if z_mask is not None:
+            in_mask = z_mask.to(torch.float32).expand(B, 1, z_mask.shape[-1])[:, :, :T].reshape(B, T).contiguous()
 
-        pre_bias = torch.empty(B, c0, device=dev, dtype=torch.float32)
-        native.speaker_linear(g2, plan.cond_w, plan.cond_b, pre_bias)
+        pre_bias = plan.speakers.conditioning(speaker_id_embedded, B)
         x = torch.empty(B, c0, T, device=dev, dtype=torch.float32)
         native.conv1d(z, plan.pre.w, x, c_in=self.in_z_channel, c_out=c0, taps=plan.pre.taps, dilation=1,
                       pad=plan.pre.pad, tile=plan.pre.tile, epilogue=native.EPI_STORE,
-                      bias=pre_bias, bias_bstride=c0)
+                      bias=pre_bias.rows, bias_bstride=pre_bias.stride, bias_index=pre_bias.index, in_mask=in_mask)
 
         L = T
         nrb = self.num_resnet_blocks

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from ... import native
-from ...engine import PackedConv, PlainConvParams, PlanCache, require_device
+from ...engine import PackedConv, PlainConvParams, PlanCache, SpeakerTables, require_device
 from .wn import WN
 
 
@@ -42,11 +42,18 @@ class CouplingPlan:
         self.post = PackedConv(post_w, post_b, device)
         self.wn = layer.wn.plan(device)
 
-    def run(self, phys: torch.Tensor, mask2, cond, cond_offset, reverse: bool, scratch):
-        """Updates the [B, 2*half, T] buffer ``phys`` in place."""
+    def run(self, phys: torch.Tensor, mask2, cond, cond_offset, reverse: bool, scratch, src0=None, src1=None):
+        """Updates the [B, 2*half, T] buffer ``phys``: the half this layer transforms is written
+        there, the other half is left as it is.  ``src0`` / ``src1``: where the conditioning half
+        and the transformed half are read from, when not from ``phys`` itself (the first two layers
+        of a pass read the caller's tensor, so that it is never copied)."""
         h = self.half
-        x0 = phys[:, h:] if self.flipped else phys[:, :h]
-        x1 = phys[:, :h] if self.flipped else phys[:, h:]
+        lo, hi = slice(0, h), slice(h, 2 * h)
+        s0 = phys if src0 is None else src0
+        s1 = phys if src1 is None else src1
+        x0 = s0[:, hi] if self.flipped else s0[:, lo]
+        x1_in = s1[:, lo] if self.flipped else s1[:, hi]
+        x1 = phys[:, lo] if self.flipped else phys[:, hi]
         hid, wn_out = scratch
         native.conv1d(x0, self.pre.w, hid, c_in=h, c_out=self.pre.rows, taps=1, dilation=1, pad=0,
                       tile=self.pre.tile, epilogue=native.EPI_STORE, bias=self.pre.bias, mask=mask2)
@@ -54,7 +61,7 @@ class CouplingPlan:
         native.conv1d(wn_out, self.post.w, x1, c_in=wn_out.shape[1], c_out=h, taps=1, dilation=1, pad=0,
                       tile=self.post.tile,
                       epilogue=native.EPI_COUPLE_REV if reverse else native.EPI_COUPLE_FWD,
-                      bias=self.post.bias, res=x1, mask=mask2)
+                      bias=self.post.bias, res=x1_in, mask=mask2)
 
 
 class ResidualCouplingLayer(nn.Module):
@@ -87,7 +94,7 @@ class ResidualCouplingLayer(nn.Module):
         B, C, T = x.shape
         phys = x.to(torch.float32).clone(memory_format=torch.contiguous_format)
         mask2 = x_mask.to(torch.float32).expand(B, 1, T).reshape(B, T).contiguous()
-        cond = plan.wn.conditioning(speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous())
+        cond = plan.wn.conditioning(speaker_id_embedded, B)
         hid = torch.empty(B, self.phoneme_embedding_dim, T, device=x.device, dtype=torch.float32)
         plan.run(phys, mask2, cond, 0, bool(reverse), (hid, torch.empty_like(hid)))
         return phys
@@ -119,30 +126,37 @@ class Flow(nn.Module):
         # one GEMV for the conditioning of every coupling layer's WN stack
         cond_w = torch.cat([l.wn.plan(device).cond_w for l in layers], 0).contiguous()
         cond_b = torch.cat([l.wn.plan(device).cond_b for l in layers], 0).contiguous()
-        return cond_w, cond_b
+        return SpeakerTables(cond_w, cond_b)
 
     @torch.no_grad()
     def forward(self, z, z_mask, speaker_id_embedded, reverse=False):
         require_device(z, "Flow.forward")
         dev = z.device
-        cond_w, cond_b = self._plans.get(dev)
+        speakers = self._plans.get(dev)
         B, C, T = z.shape
-        phys = z.to(torch.float32).clone(memory_format=torch.contiguous_format)
+        src = z if (z.dtype == torch.float32 and z.stride(2) == 1) else z.to(torch.float32).contiguous()
         mask2 = z_mask.to(torch.float32).expand(B, 1, T).reshape(B, T).contiguous()
-        g2 = speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous()
-        cond = torch.empty(B, cond_w.shape[0], device=dev, dtype=torch.float32)
-        native.speaker_linear(g2, cond_w, cond_b, cond)
-        per_layer = cond_w.shape[0] // self.n_flows
+        cond = speakers.conditioning(speaker_id_embedded, B)       # every coupling layer's WN stack at once
+        per_layer = speakers.cond_w.shape[0] // self.n_flows
         hid = torch.empty(B, self.phoneme_embedding_dim, T, device=dev, dtype=torch.float32)
         scratch = (hid, torch.empty_like(hid))
         # forward: layer f runs behind f flips; reverse: behind the n - f flips that precede
         # it in the reversed module list.  After the whole pass n flips have been applied.
+        # The input is never copied: the first layer of the pass reads both halves from it and
+        # writes the half it transforms into a fresh buffer; the second layer's conditioning half
+        # is that one, and the half it transforms is the input's other half, still untouched.
         n = self.n_flows
-        order = range(n - 1, -1, -1) if reverse else range(n)
-        for f in order:
+        order = list(range(n - 1, -1, -1) if reverse else range(n))
+        if n < 2:
+            phys = src.clone(memory_format=torch.contiguous_format)
+            src = None
+        else:
+            phys = torch.empty(B, C, T, device=dev, dtype=torch.float32)
+        for step, f in enumerate(order):
             flips = (n - f) if reverse else f
-            self.flows[2 * f].plan(dev, flipped=(flips % 2 == 1)).run(phys, mask2, cond, f * per_layer,
-                                                                     bool(reverse), scratch)
+            layer = self.flows[2 * f].plan(dev, flipped=(flips % 2 == 1))
+            layer.run(phys, mask2, cond, f * per_layer, bool(reverse), scratch,
+                      src0=src if step == 0 else None, src1=src if step < 2 else None)
         if self.n_flows % 2 == 1:
             phys = torch.flip(phys, [1])
         return phys

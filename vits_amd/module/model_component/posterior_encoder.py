@@ -65,7 +65,7 @@ class PosteriorEncoder(nn.Module):
         x = torch.empty(B, H, T, device=dev, dtype=torch.float32)
         native.conv1d(spec, plan.pre.w, x, c_in=self.in_spec_channels, c_out=H, taps=1, dilation=1, pad=0,
                       tile=plan.pre.tile, epilogue=native.EPI_STORE, bias=plan.pre.bias, mask=mask2)
-        cond = plan.wn.conditioning(speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous())
+        cond = plan.wn.conditioning(speaker_id_embedded, B)
         h = plan.wn.run(x, mask2, cond)
 
         if noise is None:

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import native
-from ...engine import PlanCache
+from ...engine import PlanCache, SpeakerRef, SpeakerTables
 
 MIN_BIN_WIDTH = 1e-3
 MIN_BIN_HEIGHT = 1e-3
@@ -168,6 +168,7 @@ class SdpPlan:
     def __init__(self, sdp: "StochasticDurationPredictor", device):
         self.cond_w = _f32(sdp.cond.weight[:, :, 0], device)
         self.cond_b = _f32(sdp.cond.bias, device)
+        self.speakers = SpeakerTables(self.cond_w, self.cond_b)
         self.pre_wt = _f32(sdp.pre.weight[:, :, 0].t(), device)
         self.pre_b = _f32(sdp.pre.bias, device)
         self.proj_wt = _f32(sdp.proj.weight[:, :, 0].t(), device)
@@ -246,14 +247,13 @@ class StochasticDurationPredictor(nn.Module):
         dev = text_encoded.device
         x = text_encoded.to(torch.float32).contiguous()
         mask2 = text_mask.to(torch.float32).expand(B, 1, T).reshape(B, T).contiguous()
-        add_vec = None
+        add_vec = add_index = None
         if speaker_id_embedded is not None:
-            add_vec = torch.empty(B, H, device=dev, dtype=torch.float32)
-            native.speaker_linear(speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous(),
-                                  plan.cond_w, plan.cond_b, add_vec)
+            cond = plan.speakers.conditioning(speaker_id_embedded, B)
+            add_vec, add_index = cond.rows, cond.index
         g = torch.empty(B, H, T, device=dev, dtype=torch.float32)
         native.dds_condition(x, plan.pre_wt, plan.pre_b, add_vec, plan.layers, plan.n_layers, plan.taps,
-                             plan.proj_wt, plan.proj_b, mask2, g)
+                             plan.proj_wt, plan.proj_b, mask2, g, add_index=add_index)
         z = noise.to(device=dev, dtype=torch.float32).contiguous()
         bufs = [torch.empty_like(z), torch.empty_like(z)]
         for i, c in enumerate(plan.couplings):
@@ -279,6 +279,8 @@ class StochasticDurationPredictor(nn.Module):
                     device=text_encoded.device, dtype=text_encoded.dtype)
             return self._reverse_on_token_kernels(text_encoded, text_mask, speaker_id_embedded, noise_scale, noise)
         x = self.pre(text_encoded)
+        if isinstance(speaker_id_embedded, SpeakerRef):
+            speaker_id_embedded = speaker_id_embedded.embedded()
         if speaker_id_embedded is not None:
             x = x + self.cond(speaker_id_embedded)
         x = self.proj(self.convs(x, text_mask)) * text_mask

@@ -22,7 +22,7 @@ import torch.nn as nn
 import os
 
 from ... import native, packing
-from ...engine import PackedConv, PlanCache, WeightNormConvParams, precision, require_device
+from ...engine import Conditioning, PackedConv, PlanCache, SpeakerTables, WeightNormConvParams, precision, require_device
 from ...packing import pair_row_order
 
 
@@ -59,22 +59,21 @@ class WNPlan:
         # conditioning GEMV: rows = 2H * n, in-conv biases folded into its bias
         self.cond_w = wn.condition_layer.effective_weight().to(device)[:, :, 0].contiguous()
         self.cond_b = cond_bias.contiguous()
+        self.speakers = SpeakerTables(self.cond_w, self.cond_b)
 
-    def conditioning(self, g2: torch.Tensor) -> torch.Tensor:
-        """g2 [B, G] -> per-(batch, layer) gate biases [B, n_layers * 2H]."""
-        out = torch.empty(g2.shape[0], self.cond_w.shape[0], device=g2.device, dtype=torch.float32)
-        native.speaker_linear(g2, self.cond_w, self.cond_b, out)
-        return out
+    def conditioning(self, speaker, batch: int) -> Conditioning:
+        """Speakers (a SpeakerRef, or embedded [B, G, 1]) -> per-(item, layer) gate biases, n_layers * 2H each."""
+        return self.speakers.conditioning(speaker, batch)
 
-    def run(self, x: torch.Tensor, mask2: torch.Tensor, cond: torch.Tensor, cond_offset: int = 0,
+    def run(self, x: torch.Tensor, mask2: torch.Tensor, cond: Conditioning, cond_offset: int = 0,
             out: torch.Tensor | None = None) -> torch.Tensor:
-        """x [B,H,T] is consumed (updated in place); mask2 [B,T]; cond [B, *] holds this
-        stack's gate biases starting at column ``cond_offset``.  Returns the masked skip sum."""
+        """x [B,H,T] is consumed (updated in place); mask2 [B,T]; ``cond`` holds this stack's gate
+        biases starting at column ``cond_offset``.  Returns the masked skip sum."""
         B, H, T = x.shape
         skip = torch.empty_like(x)
         if out is None:
             out = torch.empty_like(x)
-        cstride = cond.stride(0)
+        cstride = cond.stride
         # Measured on the MI355X (reverse flow, batch x 862 frames, one-launch layer / two launches):
         # 1: 1.37 / 0.87 ms, 4: 1.39 / 1.14, 8: 1.42 / 1.78, 16: 2.49 / 2.37.  A few thousand frames
         # give the one-launch layer a few dozen workgroups, each a serial loop over 960 channel taps,
@@ -89,17 +88,17 @@ class WNPlan:
                 dst = out if last else other
                 if last and out.data_ptr() == x.data_ptr():
                     raise native.NativeError("WN: the output buffer aliases the last layer's input")
-                native.wn_layer(x, w_in, cond[:, cond_offset + 2 * H * i:], cstride, w_rs, rc.bias, dst, skip, mask2,
-                                taps=ic.taps, dilation=ic.dilation, first=(i == 0), last=last)
+                native.wn_layer(x, w_in, cond.columns(cond_offset + 2 * H * i), cstride, w_rs, rc.bias, dst, skip, mask2,
+                                taps=ic.taps, dilation=ic.dilation, first=(i == 0), last=last, cond_index=cond.index)
                 x, other = dst, x
             return out
         acts = torch.empty_like(x)
         for i in range(self.n_layers):
             ic, rc = self.in_convs[i], self.rs_convs[i]
-            bias_view = cond[:, cond_offset + 2 * H * i:]
+            bias_view = cond.columns(cond_offset + 2 * H * i)
             native.conv1d(x, ic.w, acts, c_in=H, c_out=2 * H, taps=ic.taps, dilation=ic.dilation,
                           pad=ic.pad, tile=ic.tile, epilogue=native.EPI_GATE, bias=bias_view,
-                          bias_bstride=cstride, hidden=H)
+                          bias_bstride=cstride, bias_index=cond.index, hidden=H)
             if i < self.n_layers - 1:
                 native.conv1d(acts, rc.w, x, c_in=H, c_out=2 * H, taps=1, dilation=1, pad=0, tile=rc.tile,
                               epilogue=native.EPI_WN_MID, bias=rc.bias, res=x, out2=skip, mask=mask2,
@@ -139,6 +138,6 @@ class WN(nn.Module):
         plan = self.plan(x.device)
         B, H, T = x.shape
         mask2 = x_mask.to(torch.float32).expand(B, 1, T).reshape(B, T).contiguous()
-        cond = plan.conditioning(speaker_id_embedded.to(torch.float32).reshape(B, -1).contiguous())
+        cond = plan.conditioning(speaker_id_embedded, B)
         work = x.to(torch.float32).clone(memory_format=torch.contiguous_format)
         return plan.run(work, mask2, cond)

@@ -13,7 +13,8 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import native
+from .. import engine, native
+from ..engine import SpeakerRef
 from .model_component.decoder import Decoder
 from .model_component.flow import Flow
 from .model_component.posterior_encoder import PosteriorEncoder
@@ -61,7 +62,20 @@ class HotPathGenerator(nn.Module):
 
     @torch.no_grad()
     def embed_speaker(self, speaker_id):
+        """The embedded speakers [B, G, 1] as the reference forms them (vits_generator.py:170,191-192)."""
         return self.speaker_embedding(speaker_id).unsqueeze(-1)
+
+    def speaker_ref(self, speaker_id) -> SpeakerRef:
+        """Speaker ids bound to this generator's embedding table.  Accepted by every module here in
+        place of the embedded speakers: the speaker conditioning is then a row of a per-speaker
+        table (built once per weights), not an embedding gather and a GEMV per call."""
+        return SpeakerRef(speaker_id, self.speaker_embedding)
+
+    def set_precision(self, name):
+        """Matrix-core input precision of this generator ("fp32", "bf16", "fp32-split"; None: the
+        process default of ``engine.set_precision``), whatever other models in the process use."""
+        engine.set_module_precision(self, name)
+        return self
 
     @torch.no_grad()
     def synthesize_from_prior(self, m_p, logs_p, spec_mask, speaker_id_embedded, noise=None,
@@ -72,23 +86,25 @@ class HotPathGenerator(nn.Module):
             noise = torch.randn_like(m_p)
         z_p = m_p + noise * torch.exp(logs_p) * noise_scale
         z = self.flow(z_p, spec_mask, speaker_id_embedded=speaker_id_embedded, reverse=True)
-        return self.decoder((z * spec_mask)[:, :, :max_len], speaker_id_embedded=speaker_id_embedded)
+        # (z * spec_mask)[:, :, :max_len]: the slice is a view, the product is taken by the decoder's first conv
+        return self.decoder(z[:, :, :max_len], speaker_id_embedded=speaker_id_embedded, z_mask=spec_mask)
 
     @torch.no_grad()
     def flow_reverse_decode(self, z_p, spec_mask, speaker_id_embedded):
+        """The hot path (vits_generator.py:185-186); ``speaker_id_embedded``: [B, G, 1] or a SpeakerRef."""
         z = self.flow(z_p, spec_mask, speaker_id_embedded=speaker_id_embedded, reverse=True)
-        return self.decoder(z * spec_mask, speaker_id_embedded=speaker_id_embedded)
+        return self.decoder(z, speaker_id_embedded=speaker_id_embedded, z_mask=spec_mask)
 
     @torch.no_grad()
     def voice_conversion(self, spec_padded, spec_lengths, source_speaker_id, target_speaker_id, noise=None):
         assert self.n_speakers > 0
-        emb_source = self.embed_speaker(source_speaker_id)
-        emb_target = self.embed_speaker(target_speaker_id)
+        emb_source = self.speaker_ref(source_speaker_id)
+        emb_target = self.speaker_ref(target_speaker_id)
         z, _, _, spec_mask = self.posterior_encoder(spec_padded, spec_lengths,
                                                     speaker_id_embedded=emb_source, noise=noise)
         z_p = self.flow(z, spec_mask, speaker_id_embedded=emb_source)
         z_hat = self.flow(z_p, spec_mask, speaker_id_embedded=emb_target, reverse=True)
-        return self.decoder(z_hat * spec_mask, speaker_id_embedded=emb_target)
+        return self.decoder(z_hat, speaker_id_embedded=emb_target, z_mask=spec_mask)
 
 
 class VitsGenerator(HotPathGenerator):
@@ -137,21 +153,22 @@ class VitsGenerator(HotPathGenerator):
     def _token_stage(self, text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w):
         """Lines 169-176 of ``text_to_speech``: token-level prior and sampled durations."""
         text_encoded, m_p, logs_p, text_mask = self.text_encoder(text_padded, text_lengths)
-        g = self.embed_speaker(speaker_id)
+        g = self.speaker_ref(speaker_id) if text_padded.is_cuda else self.embed_speaker(speaker_id)
         logw = self.stochastic_duration_predictor(text_encoded, text_mask, speaker_id_embedded=g, reverse=True,
                                                   noise_scale=noise_scale_w, noise=noise_w)
         w_ceil = torch.ceil(torch.exp(logw) * text_mask * length_scale)
-        return m_p, logs_p, text_mask, w_ceil, g
+        return m_p, logs_p, text_mask, w_ceil
 
     def _front_weights_key(self):
-        """Where the captured kernels read their weights from: a graph is only good while the
-        parameters stay in the storage they had at capture (in-place loads keep it, .to() does not)."""
-        from .. import engine
+        """What the captured kernels read: packed or transposed copies of the parameters, made by
+        the plan caches for the storage and version the parameters had at capture.  A graph is only
+        good while both stay (an in-place ``load_state_dict`` keeps the storage and bumps the
+        version; ``.to()`` moves the storage), and while the precision the plans were built for does."""
         if getattr(self, "_front_params_seen", -1) != engine._registrations[0]:
             mods = (self.text_encoder, self.stochastic_duration_predictor, self.speaker_embedding)
             self._front_params = [p for m in mods for p in m.parameters()]     # the tree walk is the costly part
             self._front_params_seen = engine._registrations[0]
-        return hash(tuple(p.data_ptr() for p in self._front_params))
+        return hash((engine.module_precision(self),) + tuple((p.data_ptr(), p._version) for p in self._front_params))
 
     def _token_stage_graphed(self, text_padded, text_lengths, speaker_id, noise_w, length_scale, noise_scale_w):
         from ..graphs import GraphedCall
@@ -180,16 +197,16 @@ class VitsGenerator(HotPathGenerator):
             while len(self._front_graphs) >= self.max_front_graphs:
                 self._front_graphs.pop(next(iter(self._front_graphs)))
         self._front_graphs[key] = call                       # most recently used last
-        m_p, logs_p, text_mask, w_ceil, g = call(text_padded, text_lengths, speaker_id, noise_w)
-        return m_p, logs_p, text_mask, w_ceil, g.clone()     # g outlives this call; the rest is consumed at once
+        return call(text_padded, text_lengths, speaker_id, noise_w)     # consumed at once by the caller
 
     @torch.no_grad()
     def frame_prior(self, text_padded, text_lengths, speaker_id, length_scale=1, noise_scale_w=0.8, noise_w=None):
         """Lines 169-182 of ``text_to_speech``: token-level prior, sampled durations, hard
         monotonic path, frame-level (m_p, logs_p).  Returns (m_p, logs_p, spec_mask, g)."""
         stage = self._token_stage_graphed if (self.use_front_graph and text_padded.is_cuda) else self._token_stage
-        m_p, logs_p, text_mask, w_ceil, g = stage(text_padded, text_lengths, speaker_id, noise_w, length_scale,
-                                                  noise_scale_w)
+        m_p, logs_p, text_mask, w_ceil = stage(text_padded, text_lengths, speaker_id, noise_w, length_scale,
+                                               noise_scale_w)
+        g = self.speaker_ref(speaker_id) if m_p.is_cuda else self.embed_speaker(speaker_id)
         if m_p.is_cuda and self.use_expand_kernel and m_p.shape[2] <= native.EXPAND_MAX_TOKENS:
             # the alignment as a gather: the only host round trip is the number of frames
             frames = int(torch.clamp_min(w_ceil.sum([1, 2]), 1).max().item())

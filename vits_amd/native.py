@@ -55,6 +55,8 @@ class ConvArgs(C.Structure):
         ("navg", C.c_float),
         ("precision", C.c_int32), ("narrow", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("bias_index", _fp), ("bias_rows", C.c_int32),
+        ("in_mask", _fp),
     ]
 
 
@@ -83,6 +85,7 @@ class WnArgs(C.Structure):
         ("mask", _fp),
         ("batch", C.c_int32), ("hidden", C.c_int32), ("length", C.c_int32), ("taps", C.c_int32),
         ("dilation", C.c_int32), ("first", C.c_int32), ("last", C.c_int32),
+        ("cond_index", _fp), ("cond_rows", C.c_int32),
     ]
 
 
@@ -122,6 +125,7 @@ class DdsArgs(C.Structure):
         ("batch", C.c_int32), ("length", C.c_int32), ("n_layers", C.c_int32), ("taps", C.c_int32),
         ("pass_channel", C.c_int32), ("num_bins", C.c_int32),
         ("tail_bound", C.c_float), ("in_scale", C.c_float),
+        ("add_index", _fp), ("add_rows", C.c_int32),
     ]
 
 
@@ -301,12 +305,15 @@ _workspaces = {}
 def workspace(device):
     """Scratch for split channel loops, one per (device, stream): launches on different streams
     may overlap in time and must not share arrival counters.  Zeroed once; every launch leaves the
-    counters zero.  A stream that is being captured into a graph takes the device's capture
-    workspace (made ahead of the capture by ``ensure_capture_workspace``): capture streams come
-    and go, and a workspace made during capture would live in the graph's private pool."""
+    counters zero.  The side streams of ``branch_streams`` get theirs when they are made, so they
+    find it whether they run eagerly or inside a capture.  Any other stream that is being captured
+    into a graph takes the device's capture workspace (made ahead of the capture by
+    ``ensure_capture_workspace``): capture streams come and go, and a workspace made during capture
+    would live in the graph's private pool.  A capture that forks onto streams of its own, other
+    than those of ``branch_streams``, must keep split-loop launches on one of them."""
     index = _device_index(device)
     key = (index, torch._C._cuda_getCurrentRawStream(index))
-    ws = _workspaces.get(key)
+    ws = _workspaces.get(key)           # the side streams own theirs from birth, also while they are captured
     if ws is None:
         device = torch.device("cuda", index)
         if torch.cuda.is_current_stream_capturing():
@@ -333,7 +340,10 @@ def branch_streams(device, n: int = 2):
     while len(have) < n:
         st = torch.cuda.Stream(device=torch.device("cuda", index))
         with torch.cuda.stream(st):
-            torch.zeros(1, device=torch.device("cuda", index))
+            # its own split-loop scratch from the start: launches on it may overlap with those of
+            # the stream it branches from, eagerly and inside a capture alike
+            _workspaces[(index, st.cuda_stream)] = torch.zeros(WS_BYTES // 4, dtype=torch.float32,
+                                                               device=torch.device("cuda", index))
         have.append(st)
     return have[:n]
 
@@ -353,7 +363,8 @@ def ensure_capture_workspace(device):
 
 def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue,
            bias=None, bias_bstride=0, res=None, out2=None, out3=None, aux=None, mask=None,
-           act_in=False, in_slope=1.0, first=False, hidden=0, up_stride=0, navg=1.0, static_scratch=False):
+           act_in=False, in_slope=1.0, first=False, hidden=0, up_stride=0, navg=1.0, static_scratch=False,
+           bias_index=None, in_mask=None):
     """Enqueue one fused convolution on the current stream of ``x``'s device.  ``static_scratch``:
     through ``vk_conv1d_static`` (a split channel loop keeps its partials in the library's own device
     array: no workspace tensor, no allocation in the call)."""
@@ -379,6 +390,13 @@ def conv1d(x, w_packed, out, *, c_in, c_out, taps, dilation, pad, tile, epilogue
     if mask is not None:
         assert mask.dtype == torch.float32 and mask.is_contiguous()
         a.mask = mask.data_ptr()
+    if bias_index is not None:          # bias is a per-speaker table, bias_index[b] the row of item b
+        assert bias is not None and bias_index.dtype == torch.int64 and bias_index.is_contiguous() \
+            and bias_index.numel() == x.shape[0] and bias_index.device == x.device
+        a.bias_index, a.bias_rows = bias_index.data_ptr(), bias.shape[0]
+    if in_mask is not None:             # x is read as x * in_mask[b, t]
+        assert in_mask.dtype == torch.float32 and in_mask.is_contiguous() and in_mask.numel() == x.shape[0] * x.shape[2]
+        a.in_mask = in_mask.data_ptr()
     a.batch, a.c_in, a.c_out, a.length = x.shape[0], c_in, c_out, x.shape[2]
     a.taps, a.dilation, a.pad = taps, dilation, pad
     a.tile, a.epilogue = tile, epilogue
@@ -496,7 +514,8 @@ def wn_info(hidden: int):
     return _wn_cache[hidden]
 
 
-def wn_layer(x, w_in, cond, cond_bstride, w_rs, bias_rs, x_out, skip, mask, *, taps, dilation, first, last):
+def wn_layer(x, w_in, cond, cond_bstride, w_rs, bias_rs, x_out, skip, mask, *, taps, dilation, first, last,
+             cond_index=None):
     """One WN layer: gate conv + conditioning + tanh*sigmoid + 1x1 res/skip conv + residual, skip
     and mask updates in one launch.  ``x_out`` (the output on the last layer) must not alias ``x``."""
     assert x.is_cuda and mask.dtype == torch.float32 and mask.is_contiguous()
@@ -504,6 +523,9 @@ def wn_layer(x, w_in, cond, cond_bstride, w_rs, bias_rs, x_out, skip, mask, *, t
     a.x, a.x_bstride, a.x_cstride = _view(x)
     a.w_in, a.w_rs = w_in.data_ptr(), w_rs.data_ptr()
     a.cond, a.cond_bstride = cond.data_ptr(), cond_bstride
+    if cond_index is not None:
+        assert cond_index.dtype == torch.int64 and cond_index.is_contiguous() and cond_index.numel() == x.shape[0]
+        a.cond_index, a.cond_rows = cond_index.data_ptr(), cond.shape[0]
     a.bias_rs = bias_rs.data_ptr() if bias_rs is not None else None
     a.x_out, a.xo_bstride, a.xo_cstride = _view(x_out)
     a.skip, a.skip_bstride, a.skip_cstride = _view(skip)
@@ -535,12 +557,15 @@ def _dds_common(a, x, pre_wt, pre_b, layers, n_layers, taps, proj_wt, proj_b, ma
     return None
 
 
-def dds_condition(x, pre_wt, pre_b, add_vec, layers, n_layers, taps, proj_wt, proj_b, mask, out):
+def dds_condition(x, pre_wt, pre_b, add_vec, layers, n_layers, taps, proj_wt, proj_b, mask, out, add_index=None):
     """out = proj(DDSConv(pre(x) + add_vec)) * mask, one launch per layer: x, out [B, 192, T]; 1x1 weights
     input-major; ``layers`` packed as the header describes; add_vec [B, 192] or None."""
     a = DdsArgs()
     ws = _dds_common(a, x, pre_wt, pre_b, layers, n_layers, taps, proj_wt, proj_b, mask, out)  # noqa: F841 (kept alive)
     a.add_vec = add_vec.data_ptr() if add_vec is not None else None
+    if add_index is not None:           # add_vec is a per-speaker table [n_speakers, 192]
+        assert add_vec is not None and add_index.dtype == torch.int64 and add_index.is_contiguous()
+        a.add_index, a.add_rows = add_index.data_ptr(), add_vec.shape[0]
     B, H, T = x.shape
     flops = 2.0 * B * T * H * H * (n_layers + 2)
     L, sp = lib(), stream_ptr(x.device)
