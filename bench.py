@@ -10,7 +10,7 @@ synthetic latents already resident in HBM: 16 utterances x 862 frames (10.008 s 
 For N > 1 this process starts N ranks itself (one per GPU, fresh child processes, before
 anything here touches the GPU) unless it already is a rank of torch.distributed.run.  Every
 rank runs its own per-GPU batch (weak scaling, utterance-sharded, no collective in the hot
-path); RCCL is used for the barriers and for one all-gather of a six-number metrics row per
+path); RCCL is used for the barriers and for one all-gather of a seven-number metrics row per
 rank after each timed region.
 
 Rank 0 prints ONE JSON line: audio seconds generated per wall second (whole job), a roofline
@@ -203,6 +203,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             kept = sharding.run_shard(work, hot_path, keep="all")
+        issued = time.perf_counter() - t0                  # the Python thread is done enqueueing
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         worst, checked = 0.0, []
@@ -214,11 +215,26 @@ def main():
             worst = max(worst, float(diff.max()))
             checked.append({"bucket": b.bucket_id, "utterance": int(b.utterances[i]), "frames": int(b.lengths[i]),
                             "max_abs": float(diff.max()), "max_abs_valid": float(diff[..., :n].max())})
-        row = sharding.metrics_row(el, work, parity=worst, checksum=sharding.valid_checksum(work, kept))
+        checksum = sharding.valid_checksum(work, kept)
+        del kept
+        # Host against device on this rank's lightest and heaviest bucket.  (`issued` is not the
+        # host's own cost here: with more than a few buckets in flight the enqueueing thread waits for
+        # room in the device queue.)  The rank's host time per pass is estimated from the two.
+        ends = [min(work, key=lambda b: b.padded_frames), max(work, key=lambda b: b.padded_frames)] if work else []
+        split = sharding.host_device_split(ends, hot_path, dev)
+        host_est = steps * len(work) * sum(r["host_ms"] for r in split) / max(len(split), 1) / 1e3
+        row = sharding.metrics_row(el, work, parity=worst, checksum=checksum, host=host_est)
         table = sharding.gather_metrics(row, device=mdev)
         out = sharding.summarize(table, steps)
         out.update({"utterances": args.corpus, "steps": steps, "scaling": "strong", "checked_rank0": checked,
-                    "tol": tol, "buckets_per_rank": [len(work)] if dist is None else None})
+                    "tol": tol, "buckets_rank0": len(work),
+                    "bucket_policy": f"length-sorted, <= {sharding.MAX_ITEMS} items and <= {sharding.FRAME_BUDGET} "
+                                     f"padded frames per bucket, the {sharding.NODE_RANKS} lightest halved",
+                    "enqueue_returned_after_ms_rank0": 1e3 * issued / steps,
+                    "host_note": "per_rank_host_issue_ms_per_step: buckets x mean enqueue time of the rank's lightest "
+                                 "and heaviest bucket (device idle, no synchronisation inside); the device needs "
+                                 "per_rank_ms_per_step",
+                    "host_vs_device_rank0": split})
         return out, worst
 
     # ------------------------------------------------------------------ headline step
@@ -260,6 +276,7 @@ def main():
     with timer:
         for _ in range(args.steps):
             wav = step()
+    issued = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -280,6 +297,7 @@ def main():
 
     row = [0.0] * sharding.METRIC_COLUMNS
     row[sharding.M_ELAPSED] = elapsed
+    row[sharding.M_HOST] = issued
     row[sharding.M_VALID_FRAMES] = valid_frames_local
     row[sharding.M_PADDED_FRAMES] = padded_local
     row[sharding.M_UTTERANCES] = utts_local
@@ -365,6 +383,7 @@ def main():
             "per_gpu_value": job["value"] / world,
             "ranks_seen": job["ranks_seen"],
             "per_rank_ms_per_step": job["per_rank_ms_per_step"],
+            "per_rank_host_issue_ms_per_step": job["per_rank_host_issue_ms_per_step"],
             "load_imbalance": job["load_imbalance"],
             "parity": {"max_abs": job["parity_max_abs"], "items": items, "tol": tol,
                        "against": "CPU oracle on the same latents, every rank's first and last item",

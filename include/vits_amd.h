@@ -170,8 +170,10 @@ int64_t vk_conv1d_workspace_bytes(const vk_conv_args* a);
  * workspace: `workspace` / `workspace_bytes` are ignored and the call never allocates or frees
  * device memory.  No counterpart in the reference; it is for callers that cannot allocate:
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
- * A launch that would need more scratch than the array holds is refused with VK_E_UNSUPPORTED
- * (use vk_conv1d with a workspace).  All calls on one GPU share that GPU's array: calls that
+ * The array is a fixed VK_STATIC_SCRATCH_BYTES: a launch whose widest split would need more takes
+ * the widest split that fits (none at all in the end), so its result can differ from vk_conv1d's
+ * with a large workspace in the last bits, never in validity; a launch whose split fits is
+ * bit-identical to vk_conv1d's.  All calls on one GPU share that GPU's array: calls that
  * overlap in time on one GPU (different streams) race; calls on one stream do not. */
 #define VK_STATIC_SCRATCH_BYTES (VK_WS_COUNTER_BYTES + (32 << 20))
 int vk_conv1d_static(const vk_conv_args* a, void* stream);

@@ -680,3 +680,43 @@ def test_split_channel_loop_workspace_contract():
     a.batch, a.length, a.narrow = 16, 6896, 0
     assert L_.vk_conv1d_workspace_bytes(C.byref(a)) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sliced", [False, True])
+def test_split_channel_loop_is_run_to_run_identical(sliced):
+    """A launch too small for the GPU splits its channel loop over workgroups that meet in scratch
+    memory (arrival counter + partial tiles, no fence): many back-to-back launches of one
+    convolution must all give the bits of the first, and those must match the unsplit launch to
+    rounding.  A lost or stale partial, or a miscounted arrival, shows up as a differing repeat."""
+    from vits_amd.engine import choose_tile
+    g = torch.Generator().manual_seed(5)
+    before = native.SPLIT_SMALL_LAUNCHES
+    try:
+        for cin, cout, k, dil, B, L in [(256, 256, 3, 1, 1, 2064), (256, 256, 11, 5, 1, 2064), (192, 384, 5, 1, 1, 258),
+                                        (512, 256, 7, 1, 2, 33), (128, 128, 7, 3, 1, 1500), (64, 64, 11, 1, 1, 3000)]:
+            x = torch.randn(B, cin, L, generator=g).to(DEV)
+            w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+            tile = choose_tile(cout)
+            ti = native.tile_info(tile)
+            wp = (packing.pack_conv_weight_split(w.to(DEV), ti.ck_split, ti.rows_per_block) if sliced
+                  else packing.pack_conv_weight(w, ti.ck, ti.rows_per_block).to(DEV))
+            pad = (k - 1) * dil // 2
+
+            def run(split, out):
+                native.SPLIT_SMALL_LAUNCHES = split
+                native.conv1d(x, wp, out, c_in=cin, c_out=cout, taps=k, dilation=dil, pad=pad, tile=tile,
+                              epilogue=native.EPI_STORE)
+            ref = torch.empty(B, cout, L, device=DEV)
+            run(False, ref)
+            first = torch.empty_like(ref)
+            run(True, first)
+            outs = [torch.empty_like(ref) for _ in range(100)]
+            for o in outs:
+                run(True, o)
+            torch.cuda.synchronize()
+            differing = sum(int(not torch.equal(o, first)) for o in outs)
+            assert differing == 0, (cin, cout, k, L, differing)
+            assert (first - ref).abs().max().item() <= 1e-4, (cin, cout, k, L)
+    finally:
+        native.SPLIT_SMALL_LAUNCHES = before

@@ -79,12 +79,15 @@ def test_static_scratch_entry_without_a_split_and_beyond_its_size():
     with_ws, static, ref = _both_entries(64, 64, 7, 3, 4, 9000, 431)
     assert torch.equal(with_ws, static)
     assert (static.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    # wide tiles, 100 workgroups x 8 splits x 64 KiB of partials: more than the array holds
+    # wide tiles, 100 workgroups x 8 splits x 64 KiB of partials: more than the array holds.  The
+    # static entry narrows the split to what fits (5 shares) and runs; the workspace entry, given
+    # a workspace of the array's size, says what it would need
     B, cin, cout, k, L = 1, 256, 256, 7, 6400
     x = _rand(B, cin, L, seed=441).to(DEV)
+    w = _rand(cout, cin, k, seed=442) / (cin * k) ** 0.5
     ti = native.tile_info(native.TILE_M128)
-    wp = packing.pack_conv_weight(_rand(cout, cin, k, seed=442), ti.ck, ti.rows_per_block).to(DEV)
-    out = torch.empty(B, cout, L, device=DEV)
+    wp = packing.pack_conv_weight(w, ti.ck, ti.rows_per_block).to(DEV)
+    out = torch.full((B, cout, L), float("nan"), device=DEV)
     a = native.ConvArgs()
     a.x, a.x_bstride, a.x_cstride = native._view(x)
     a.out, a.out_bstride, a.out_cstride = native._view(out)
@@ -93,8 +96,16 @@ def test_static_scratch_entry_without_a_split_and_beyond_its_size():
     a.taps, a.dilation, a.pad, a.tile, a.epilogue, a.narrow = k, 1, 3, native.TILE_M128, native.EPI_STORE, 0
     lib = native.lib()
     need = lib.vk_conv1d_workspace_bytes(C.byref(a))
-    assert need == 65536 + 100 * 8 * 128 * 128 * 4 and need > 65536 + (32 << 20)
-    assert lib.vk_conv1d_static(C.byref(a), native.stream_ptr(x.device)) == -2
+    static_bytes = 65536 + (32 << 20)
+    assert need == 65536 + 100 * 8 * 128 * 128 * 4 and need > static_bytes
+    for _ in range(2):
+        assert lib.vk_conv1d_static(C.byref(a), native.stream_ptr(x.device)) == 0, lib.vk_last_error().decode()
+    torch.cuda.synchronize()
+    ref = F.conv1d(x.cpu(), w, None, padding=3)
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    small = torch.zeros(static_bytes // 4, device=DEV)
+    a.workspace, a.workspace_bytes = small.data_ptr(), static_bytes
+    assert lib.vk_conv1d(C.byref(a), native.stream_ptr(x.device)) == -2
     msg = lib.vk_last_error().decode()
-    assert "vk_conv1d_static" in msg and "scratch" in msg and str(need) in msg
+    assert "scratch" in msg and str(need) in msg
     torch.cuda.synchronize()

@@ -73,7 +73,8 @@ static int64_t gemm_rows(const vk_conv_args* a)
 // `ws` / `ws_bytes`: the scratch a split channel loop may use (null: the launch does not split);
 // `query`: only work out how much it would use (*ws_need), whatever scratch there is.
 static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, int* vec,
-                  void* ws, int64_t ws_bytes, int64_t* ws_need, bool query, const char* who = "vk_conv1d")
+                  void* ws, int64_t ws_bytes, int64_t* ws_need, bool query, const char* who = "vk_conv1d",
+                  bool fit_split = false)
 {
     if (!a) return vk_fail(VK_E_ARG, "vk_conv1d: null argument block");
     if (!a->x || !a->w || !a->out) return vk_fail(VK_E_ARG, "vk_conv1d: null x / w / out pointer");
@@ -197,7 +198,8 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
     // The sliced-fp32 kernel walks its tiles in an order of its own.
     // (Diagnostic build: VK_XCD_MAP=0 / 1 forces it off / on for every precision.)
     static const int xcd_env = diag_env("VK_XCD_MAP", -1);
-    d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : !split);
+    d->xcd_map = d->n_rowblk > 1 && (xcd_env >= 0 ? xcd_env != 0 : !split) &&
+                 ((int64_t)d->n_tiles * a->batch + 7) / 8 * 8 * d->n_rowblk <= 0x7fffffffLL;
     // A launch too small for 256 CUs splits its channel loop over several workgroups per output
     // tile (fp32 and sliced-fp32 kernels): as many as bring it to about four workgroups per CU, at least two
     // chunks each, at most 8 (one utterance of 3 s, decoder: 2.07 ms at two per CU, 1.96 ms at four).
@@ -215,15 +217,24 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
         if (k > 8) k = 8;
         if (split)                                   // the sliced-fp32 kernel's pipeline wants equal shares
             while (k > 1 && d->nchunk % k) --k;
-        if (k > 1) {
-            *ws_need = VK_WS_COUNTER_BYTES + wgs * k * (int64_t)rows_blk * TN * 4;
-            if (!query) {
-                if (*ws_need > ws_bytes) {
-                    snprintf(g_err, sizeof(g_err), "%s: the split channel loop of this launch needs %lld bytes of "
-                             "scratch, %lld are there", who, (long long)*ws_need, (long long)ws_bytes);
-                    return VK_E_UNSUPPORTED;
-                }
+        auto need = [&](int kk) { return VK_WS_COUNTER_BYTES + wgs * kk * (int64_t)rows_blk * TN * 4; };
+        if (k > 1) *ws_need = need(k);
+        if (k > 1 && !query) {
+            // less scratch than the widest split wants.  A caller's workspace: an error the caller
+            // can act on.  The library's own array (`fit_split`): a narrower split (for the sliced
+            // kernel the next divisor of the chunk count), down to none at all - the result is the
+            // same to rounding either way, and a caller that cannot allocate has no other way out
+            if (need(k) > ws_bytes && !fit_split) {
+                snprintf(g_err, sizeof(g_err), "%s: the split channel loop of this launch needs %lld bytes of "
+                         "scratch, %lld are there", who, (long long)*ws_need, (long long)ws_bytes);
+                return VK_E_UNSUPPORTED;
+            }
+            while (k > 1 && (need(k) > ws_bytes || (split && d->nchunk % k))) --k;
+            if (k > 1) {
                 if ((uintptr_t)ws % 16) return vk_fail(VK_E_ARG, "vk_conv1d: workspace must be 16-byte aligned");
+                if (wgs * (int64_t)sizeof(unsigned) > VK_WS_COUNTER_BYTES) k = 1;      // (cannot happen below 512 tiles)
+            }
+            if (k > 1) {
                 d->ksplit = k;
                 d->ws = static_cast<float*>(ws);
             }
@@ -233,7 +244,7 @@ static int derive(const vk_conv_args* a, ConvDev* d, dim3* grid, size_t* lds, in
         d->xcd_map = 0;
         *grid = dim3((unsigned)d->n_tiles, (unsigned)(d->n_rowblk * d->ksplit), (unsigned)a->batch);
     } else if (d->xcd_map)
-        *grid = dim3((unsigned)(8 * ((d->n_tiles + 7) / 8) * d->n_rowblk), 1, (unsigned)a->batch);
+        *grid = dim3((unsigned)(8 * (((int64_t)d->n_tiles * a->batch + 7) / 8) * d->n_rowblk), 1, 1);
     else
         *grid = dim3((unsigned)d->n_tiles, (unsigned)d->n_rowblk, (unsigned)a->batch);
     *lds = split ? vk_split_lds_bytes(TN, ck)
@@ -300,8 +311,8 @@ extern "C" int vk_conv1d_static(const vk_conv_args* a, void* stream)
     int rc = static_scratch(&sp);
     if (rc != VK_OK) return rc;
     ConvDev d; dim3 grid; size_t lds = 0; int vec = 0; int64_t need = 0;
-    rc = derive(a, &d, &grid, &lds, &vec, sp, VK_STATIC_SCRATCH_BYTES, &need, false, "vk_conv1d_static");
-    if (rc != VK_OK) return rc;            // includes: more scratch needed than the array holds
+    rc = derive(a, &d, &grid, &lds, &vec, sp, VK_STATIC_SCRATCH_BYTES, &need, false, "vk_conv1d_static", true);
+    if (rc != VK_OK) return rc;            // (a split wider than the array holds has been narrowed to fit)
     if (d.ksplit > 1) {
         // the arrival counters of this launch's output tiles start at zero whatever ran before
         const size_t tiles = (size_t)d.n_tiles * d.n_rowblk * a->batch;

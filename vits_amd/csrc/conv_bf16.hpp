@@ -225,13 +225,15 @@ conv_bf16_kernel(const ConvDev d)
     const int wn   = w / WM;
     const int half = lane >> 5;
     const int l31  = lane & 31;
-    const int b    = blockIdx.z;
+    int b = blockIdx.z;
     int tile = blockIdx.x, rowblk = blockIdx.y;
     if (d.xcd_map) {                                   // see conv_mfma_kernel: row blocks of a time tile share an XCD
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         rowblk = slot % d.n_rowblk;
-        tile = (slot / d.n_rowblk) * 8 + xcd;
-        if (tile >= d.n_tiles) return;
+        const int gt = (slot / d.n_rowblk) * 8 + xcd;
+        if (gt >= d.n_tiles * p.batch) return;
+        b = gt / d.n_tiles;
+        tile = gt - b * d.n_tiles;
     }
     const int t0   = tile * TN;
     const int mt0  = (rowblk * WM + wm) * A_REP;

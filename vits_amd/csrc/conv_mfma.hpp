@@ -565,6 +565,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& d, f32x16 (&acc)[A_
 // cache-wide write-back or invalidate is needed: a device-scope fence costs a small launch
 // about 40 us on the 8-XCD part, more than the split saves.
 // `arrived`: one LDS word nobody else uses at this point; every wave of the workgroup calls this.
+// The ordering of the partial stores before the arrival count rests on two properties of the gfx9
+// family: vmcnt counts stores, and device-scope stores are written through.  A target with a
+// separate store counter would compile this and race.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "vk_splitk_exchange: written for gfx942 / gfx950 (stores counted by vmcnt, write-through device-scope stores)"
+#endif
 template <int A_REP, int B_REP, int NW>
 __device__ __forceinline__ bool vk_splitk_exchange(const ConvDev& d, f32x16 (&acc)[A_REP][B_REP], int b, int tile,
                                                    int rowblk, int split, int w, int lane, unsigned* arrived)
@@ -638,14 +644,18 @@ conv_mfma_kernel(const ConvDev d)
     const int wn   = w / WM;
     const int half = lane >> 5;
     const int l31  = lane & 31;
-    const int b    = blockIdx.z;
+    int b = blockIdx.z;
     int tile = blockIdx.x, rowblk = blockIdx.y, split = 0;
     if (d.xcd_map) {
-        // hardware deals consecutive workgroup ids round-robin over the 8 XCDs
+        // hardware deals consecutive workgroup ids round-robin over the 8 XCDs; the time tiles of
+        // all batch items form one sequence that is dealt over the XCDs eight at a time, so the XCDs'
+        // shares differ by one tile at most however few tiles an item has
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         rowblk = slot % d.n_rowblk;
-        tile = (slot / d.n_rowblk) * 8 + xcd;
-        if (tile >= d.n_tiles) return;                 // padding of the last tile group (whole workgroup leaves)
+        const int gt = (slot / d.n_rowblk) * 8 + xcd;
+        if (gt >= d.n_tiles * p.batch) return;         // padding of the last tile group (whole workgroup leaves)
+        b = gt / d.n_tiles;
+        tile = gt - b * d.n_tiles;
     } else if (d.ksplit > 1) {
         split = blockIdx.y / d.n_rowblk;
         rowblk = blockIdx.y - split * d.n_rowblk;

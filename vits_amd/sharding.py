@@ -25,9 +25,16 @@ def synthetic_corpus(n: int, seed: int = 999, n_speakers: int = 100):
     return frames, spk
 
 
-def make_buckets(frames, max_items: int = 16, frame_budget: int = 16 * 862):
+MAX_ITEMS, FRAME_BUDGET = 96, 16 * 862
+
+
+def make_buckets(frames, max_items: int = MAX_ITEMS, frame_budget: int = FRAME_BUDGET):
     """Sort by length (longest first) and cut into buckets of at most ``max_items`` items whose
-    padded size items * longest stays within ``frame_budget``.  Returns lists of utterance ids."""
+    padded size items * longest stays within ``frame_budget``.  Returns lists of utterance ids.
+    The budget, not the item count, is what binds (16 utterances of 10 s; 80 of 2 s): a bucket is
+    one launch sequence, and the GPU runs a bucket of 2,752 frames (16 x 2 s) at 81 % of the frames
+    per second it reaches on 13,792 (measured: 15.96 ms against 67.1 ms), so every bucket is filled
+    to the same number of padded frames whatever the length of its utterances."""
     order = np.argsort(-np.asarray(frames), kind="stable")
     buckets, cur = [], []
     for i in order:
@@ -39,6 +46,23 @@ def make_buckets(frames, max_items: int = 16, frame_budget: int = 16 * 862):
     if cur:
         buckets.append(cur)
     return buckets
+
+
+def split_for_ranks(frames, buckets, world: int):
+    """Full buckets are all about as heavy as each other, so a greedy assignment over ``world``
+    ranks can end up to one bucket apart (2.9 % at 8 ranks and 148 buckets).  Halving the ``world``
+    lightest buckets gives it small pieces to even the ranks out with (0.3 %), at the price of
+    ``world`` launch sequences of half the size."""
+    if world <= 1:
+        return [list(b) for b in buckets]
+    light = set(sorted(range(len(buckets)), key=lambda j: bucket_cost(frames, buckets[j]))[:world])
+    out = []
+    for j, b in enumerate(buckets):
+        if j in light and len(b) >= 2:
+            out += [list(b[:len(b) // 2]), list(b[len(b) // 2:])]
+        else:
+            out.append(list(b))
+    return out
 
 
 def bucket_cost(frames, bucket) -> int:
@@ -68,10 +92,17 @@ def gather_metrics(values, device=None):
     return torch.stack(out).cpu()
 
 
-def rank_shard(frames, spk, world: int, rank: int, max_items: int = 16, frame_budget: int = 16 * 862):
+NODE_RANKS = 8          # GPUs of a node: the buckets are cut for this many ranks whatever the world size
+
+
+def rank_shard(frames, spk, world: int, rank: int, max_items: int = MAX_ITEMS, frame_budget: int = FRAME_BUDGET,
+               balance_ranks: int = NODE_RANKS):
     """The buckets rank ``rank`` of ``world`` processes: a list of
-    (bucket id, utterance ids, lengths [n] int64, speaker ids [n] int64), heaviest first."""
-    buckets = make_buckets(frames, max_items, frame_budget)
+    (bucket id, utterance ids, lengths [n] int64, speaker ids [n] int64), heaviest first.
+    The buckets themselves do not depend on ``world`` (an utterance's waveform depends on the
+    padded length of its bucket, the decoder being unmasked, so a corpus must be cut the same way
+    on 1, 2, 4 or 8 ranks to give the same samples): they are always cut for ``balance_ranks``."""
+    buckets = split_for_ranks(frames, make_buckets(frames, max_items, frame_budget), max(balance_ranks, world))
     parts, _ = assign_buckets(frames, buckets, world)
     shard = []
     for bi in parts[rank]:
@@ -82,8 +113,8 @@ def rank_shard(frames, spk, world: int, rank: int, max_items: int = 16, frame_bu
 
 
 # columns of the per-rank metrics row every rank contributes after the timed region
-M_ELAPSED, M_VALID_FRAMES, M_PADDED_FRAMES, M_UTTERANCES, M_PARITY, M_CHECKSUM = range(6)
-METRIC_COLUMNS = 6
+M_ELAPSED, M_VALID_FRAMES, M_PADDED_FRAMES, M_UTTERANCES, M_PARITY, M_CHECKSUM, M_HOST = range(7)
+METRIC_COLUMNS = 7      # M_HOST: seconds the rank's Python thread needed to enqueue the timed work (0: not measured)
 
 
 def summarize(table, steps: int, hop: int = 256, sample_rate: int = 22050):
@@ -98,6 +129,7 @@ def summarize(table, steps: int, hop: int = 256, sample_rate: int = 22050):
         "ms_per_step": 1e3 * slowest / steps,
         "ranks_seen": int(t.shape[0]),
         "per_rank_ms_per_step": [1e3 * float(e) / steps for e in elapsed],
+        "per_rank_host_issue_ms_per_step": [1e3 * float(h) / steps for h in t[:, M_HOST]],
         "per_rank_value": [float(f) * hop / sample_rate * steps / float(e)
                            for f, e in zip(t[:, M_VALID_FRAMES], elapsed)],
         "load_imbalance": slowest / float(elapsed.mean()),
@@ -150,6 +182,32 @@ def run_shard(work, hot_path, keep=None):
     return kept
 
 
+def host_device_split(work, hot_path, device, reps: int = 3):
+    """Per bucket of ``work``: the time this thread needs to enqueue one pass of ``hot_path`` (device
+    idle at the start, nothing synchronised inside) and the time the device needs for it (back to
+    back passes, the queue never dry).  A rank keeps its GPU busy while the first stays below the
+    second.  Returns a list of dicts (bucket id, batch, frames, host_ms, device_ms)."""
+    import time
+    rows = []
+    for b in work:
+        hot_path(b.z, b.mask, b.speakers)
+        host = []
+        for _ in range(reps):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            hot_path(b.z, b.mask, b.speakers)
+            host.append(time.perf_counter() - t0)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hot_path(b.z, b.mask, b.speakers)
+        torch.cuda.synchronize(device)
+        dev_s = (time.perf_counter() - t0) / reps
+        rows.append({"bucket": b.bucket_id, "batch": int(b.lengths.numel()), "frames": int(b.lengths.max()),
+                     "host_ms": 1e3 * sorted(host)[len(host) // 2], "device_ms": 1e3 * dev_s})
+    return rows
+
+
 def valid_checksum(work, outputs, hop: int = 256) -> float:
     """Sum of the valid samples of every kept output (float64), a per-rank fingerprint that
     does not depend on how buckets were dealt to ranks."""
@@ -164,9 +222,10 @@ def valid_checksum(work, outputs, hop: int = 256) -> float:
     return total
 
 
-def metrics_row(elapsed, work, parity=0.0, checksum=0.0):
+def metrics_row(elapsed, work, parity=0.0, checksum=0.0, host=0.0):
     row = [0.0] * METRIC_COLUMNS
     row[M_ELAPSED] = float(elapsed)
+    row[M_HOST] = float(host)
     row[M_VALID_FRAMES] = float(sum(b.valid_frames for b in work))
     row[M_PADDED_FRAMES] = float(sum(b.padded_frames for b in work))
     row[M_UTTERANCES] = float(sum(len(b.utterances) for b in work))
