@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 8
+#define VK_ABI_VERSION 9
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -228,20 +228,21 @@ int vk_wn_query(int hidden, vk_tile_info* info);
 int vk_wn_layer(const vk_wn_args* a, void* stream);
 
 /* ---- a whole multi-receptive-field stage in one launch ------------------------------
- *   out = ( sum_r resblock_r(x) ) / n_blocks                       (decoder.py:119-125)
+ *   out = ( acc + sum_r resblock_r(x) ) / navg                     (decoder.py:119-125)
  *   resblock_r: for each pair j: h = conv1_rj(lrelu(x_r)); x_r = conv2_rj(lrelu(h)) + x_r
  *                                                                  (decoder.py:46-61)
  * conv1_rj has taps[r] taps and dilation[r][j], conv2_rj taps[r] taps and dilation 1, both
  * "same" padded.  The residual stream and the sum over the resblocks (kernel sizes) stay in
  * registers, the activated conv inputs in LDS; only x is read and out written.  Built for
- * VK_PREC_BF16 (bf16 matrix-core inputs, fp32 accumulation) and the channel widths
+ * VK_PREC_BF16 (bf16 matrix-core inputs, fp32 accumulation) and VK_PREC_F32 (the exact fp32
+ * matrix instruction; 32 and 64 channels) and the channel widths
  * vk_mrf_query accepts: 32 and 64 channels take up to VK_MRF_MAX_BLOCKS resblocks per launch,
  * 128 and 256 channels one (vk_tile_info.max_blocks; a single resblock is its own mean, so
  * out = resblock(x): the three pairs of a resblock chained without touching HBM).  The
  * receptive half-width of every resblock, sum_j (taps[r]-1)/2 * (dilation[r][j] + 1), must not
  * exceed 64; a workgroup recomputes that many columns on either side of its outputs, so the
- * launch pays off for short kernels.  Weights are packed like vk_resblock_pair's for
- * VK_PREC_BF16 (vk_mrf_query reports ck_bf16 and rows_per_block).  `out` must not overlap `x`. */
+ * launch pays off for short kernels.  Weights are packed like vk_resblock_pair's for the same
+ * precision (vk_mrf_query reports ck or ck_bf16 and rows_per_block).  `out` must not overlap `x`. */
 #define VK_MRF_MAX_BLOCKS 4
 #define VK_MRF_MAX_PAIRS  4
 typedef struct {
@@ -256,7 +257,13 @@ typedef struct {
     const void*  w2[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
     const float* bias2[VK_MRF_MAX_BLOCKS][VK_MRF_MAX_PAIRS];
     float   slope;
-    int32_t precision;                                                 /* VK_PREC_BF16 */
+    int32_t precision;                                                 /* VK_PREC_BF16 or VK_PREC_F32 */
+    /* Sum over resblocks carried from launch to launch (decoder.py:124): the resblocks of a stage
+     * may be spread over several launches, each with the halo of its own resblocks only; a later
+     * launch adds the earlier ones' sum `acc` (same indexing as out; may be the same view as out;
+     * NULL: none) and the last one divides by the stage's resblock count `navg` (1: no division). */
+    const float* acc;     int64_t acc_bstride; int64_t acc_cstride;
+    float   navg;
 } vk_mrf_args;
 
 int vk_mrf_query(int channels, int precision, vk_tile_info* info);

@@ -552,9 +552,90 @@ def test_bf16_fused_mrf_stage(ch, B, L, kernels, dils):
     assert err.pow(2).mean().sqrt().item() <= 1.5 * noise_ref + 1e-6
 
 
+# ---- the same stage / resblock chain on the exact fp32 matrix instruction ----
+def _mrf_blocks(ch, kernels, dils, pack, seed=310):
+    ref_blocks, dev_blocks = [], []
+    for k in kernels:
+        rp, dp = [], []
+        for d in dils:
+            w1 = _rand(ch, ch, k, seed=seed) / (ch * k) ** 0.5
+            w2 = _rand(ch, ch, k, seed=seed + 1) / (ch * k) ** 0.5
+            b1, b2 = _rand(ch, seed=seed + 2) * 0.3, _rand(ch, seed=seed + 3) * 0.3
+            seed += 4
+            rp.append((w1, b1, w2, b2, d))
+            dp.append((pack(w1).to(DEV), b1.to(DEV), pack(w2).to(DEV), b2.to(DEV), d))
+        ref_blocks.append((k, rp))
+        dev_blocks.append((k, dp))
+    return ref_blocks, dev_blocks
+
+
+@pytest.mark.parametrize("ch,B,L,kernels,dils", [
+    (32, 2, 1, (3,), (1, 3, 5)),               # a single sample
+    (32, 2, 37, (3,), (1, 3, 5)),              # the reach (12) against a short signal
+    (32, 1, 488, (3,), (1, 3, 5)),             # exactly one workgroup of outputs at reach 12
+    (32, 3, 489, (3,), (1, 3, 5)),             # one column into the second workgroup
+    (32, 2, 2001, (3,), (1, 3, 5)),            # odd length, several workgroups
+    (64, 2, 489, (3,), (1, 3, 5)),
+    (64, 1, 1500, (3,), (1, 3, 5)),
+    (32, 2, 700, (3, 7, 11), (1, 3, 5)),       # the whole stage: three kernel sizes summed in registers
+    (64, 1, 500, (3, 7, 11), (1, 3, 5)),
+    (64, 2, 393, (11, 7), (1, 5)),             # two resblocks of two pairs, longest reach first
+    (32, 1, 300, (5,), (2, 1)),
+])
+def test_fp32_fused_mrf_stage(ch, B, L, kernels, dils):
+    """decoder.py:119-125 around :46-61 as chains of F.conv1d against one launch."""
+    mi = native.mrf_info(ch, native.PREC_F32)
+    assert mi is not None and mi.max_blocks == 4
+    x = _rand(B, ch, L, seed=301)
+    ref_blocks, dev_blocks = _mrf_blocks(ch, kernels, dils, lambda w: packing.pack_conv_weight(w, mi.ck, mi.rows_per_block))
+    ref = _mrf_reference(x, ref_blocks, rnd=lambda t: t)
+    xd = x.to(DEV)
+    out = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.mrf_stage(xd, out, dev_blocks, slope=0.1)
+    _close(out, ref, "stage in one launch")
+    # one launch per resblock, the sum carried through `out`, the last launch dividing
+    out2 = torch.full((B, ch, L), float("nan"), device=DEV)
+    for r, blk in enumerate(dev_blocks):
+        native.mrf_stage(xd, out2, [blk], slope=0.1, acc=out2 if r else None,
+                         navg=len(dev_blocks) if r + 1 == len(dev_blocks) else 1)
+    _close(out2, ref, "one launch per resblock")
+    if len(kernels) > 1:
+        assert torch.equal(out2, out)          # same products, same order of sums
+    # a channel-strided view of a wider tensor as input
+    wide = torch.zeros(B, ch + 3, L, device=DEV)
+    wide[:, 3:] = xd
+    out3 = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.mrf_stage(wide[:, 3:], out3, dev_blocks, slope=0.1)
+    assert torch.equal(out3, out)
+
+
+@pytest.mark.parametrize("L", [37, 2001])
+def test_fp32_resblock_chain_is_bit_identical_to_its_pair_launches(L):
+    """32 channels: the chained launch runs the pair kernel's fma chains in the same order."""
+    ch, k = 32, 3
+    pi = native.pair_info(ch)
+    mi = native.mrf_info(ch, native.PREC_F32)
+    assert (pi.ck, pi.rows_per_block) == (mi.ck, mi.rows_per_block)
+    x = _rand(2, ch, L, seed=401).to(DEV)
+    _, dev_blocks = _mrf_blocks(ch, (k,), (1, 3, 5), lambda w: packing.pack_conv_weight(w, mi.ck, mi.rows_per_block), seed=410)
+    prev = _rand(2, ch, L, seed=402).to(DEV)
+    chained = torch.empty_like(x)
+    native.mrf_stage(x, chained, dev_blocks, slope=0.1, acc=prev, navg=3)
+    cur, bufs = x, [torch.empty_like(x), torch.empty_like(x)]
+    pairs = dev_blocks[0][1]
+    for j, (w1, b1, w2, b2, d) in enumerate(pairs):
+        last = j + 1 == len(pairs)
+        dst = bufs[j & 1]
+        native.resblock_pair(cur, w1, b1, w2, b2, dst, taps=k, dilation=d, slope=0.1,
+                             epilogue=native.EPI_RESID_AVG if last else native.EPI_RESID,
+                             acc=prev if last else None, navg=3.0)
+        cur = dst
+    assert torch.equal(chained, cur)
+
+
 def test_fused_mrf_stage_rejects_bad_arguments():
     assert native.mrf_info(512, native.PREC_BF16) is None
-    assert native.mrf_info(32, native.PREC_F32) is None
+    assert native.mrf_info(128, native.PREC_F32) is None and native.mrf_info(32, native.PREC_F32_SPLIT) is None
     assert native.mrf_info(32, native.PREC_BF16).max_blocks == 4 and native.mrf_info(128, native.PREC_BF16).max_blocks == 1
     mi = native.mrf_info(32, native.PREC_BF16)
     w = packing.pack_conv_weight_bf16(_rand(32, 32, 11, seed=1), mi.ck_bf16, mi.rows_per_block).to(DEV)

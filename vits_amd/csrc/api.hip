@@ -10,6 +10,7 @@
 #include "conv_split.hpp"
 #include "wn_layer.hpp"
 #include "mrf_stage.hpp"
+#include "mrf_stage_f32.hpp"
 #include "api_internal.hpp"
 
 static thread_local char g_err[512] = "";
@@ -556,9 +557,13 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
 extern "C" int vk_mrf_query(int channels, int precision, vk_tile_info* info)
 {
     if (!info) return vk_fail(VK_E_ARG, "vk_mrf_query: null info");
-    const MrfGeom* G = precision == VK_PREC_BF16 ? vk_mrf_geom(channels) : nullptr;
-    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_query: the fused stage is built for bf16 inputs at 32, 64, 128 and 256 channels");
-    info->ck = 0; info->ck_bf16 = 32; info->ck_split = 0;
+    const MrfGeom* G = precision == VK_PREC_BF16 ? vk_mrf_geom(channels) :
+                       precision == VK_PREC_F32 ? vk_mrf_f32_geom(channels) : nullptr;
+    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_query: the fused stage is built for bf16 inputs at 32, 64, 128 and 256 "
+                                             "channels and for fp32 at 32 and 64");
+    info->ck = precision == VK_PREC_F32 ? 32 : 0;
+    info->ck_bf16 = precision == VK_PREC_BF16 ? 32 : 0;
+    info->ck_split = 0;
     info->rows_per_block = 32;
     info->time_tile = vk_mrf_window(*G) - 2 * VK_MRF_HALO;       // at least this many output columns per workgroup
     info->a_rep = 1;
@@ -570,12 +575,16 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
 {
     if (!a) return vk_fail(VK_E_ARG, "vk_mrf_stage: null argument block");
     if (!a->x || !a->out) return vk_fail(VK_E_ARG, "vk_mrf_stage: null x / out pointer");
-    if (a->precision != VK_PREC_BF16) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for VK_PREC_BF16");
-    const MrfGeom* G = vk_mrf_geom(a->channels);
-    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for 32, 64, 128 and 256 channels");
+    const bool f32 = a->precision == VK_PREC_F32;
+    if (!f32 && a->precision != VK_PREC_BF16) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for VK_PREC_BF16 and VK_PREC_F32");
+    const bool single = a->n_blocks == 1;
+    const MrfGeom* G = f32 ? vk_mrf_f32_geom(a->channels, single) : vk_mrf_geom(a->channels, single);
+    if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: built for 32, 64, 128 and 256 channels (fp32: 32 and 64)");
     if (a->batch <= 0 || a->batch > 65535 || a->length <= 0) return vk_fail(VK_E_ARG, "vk_mrf_stage: bad batch or length");
     if (a->n_blocks < 1 || a->n_blocks > (G->sum ? VK_MRF_MAX_BLOCKS : 1) || a->n_pairs < 1 || a->n_pairs > VK_MRF_MAX_PAIRS)
         return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: 1..4 resblocks (one at 128 / 256 channels) of 1..4 pairs");
+    if (!(a->navg >= 1.0f)) return vk_fail(VK_E_ARG, "vk_mrf_stage: navg must be at least 1");
+    if (a->acc && (a->acc_cstride < 0 || a->acc_bstride < 0)) return vk_fail(VK_E_ARG, "vk_mrf_stage: negative stride");
     if (!(a->slope >= 0.0f && a->slope <= 1.0f)) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: slope must lie in [0, 1]");
     if (a->x_cstride < 0 || a->out_cstride < 0 || a->x_bstride < 0 || a->out_bstride < 0)
         return vk_fail(VK_E_ARG, "vk_mrf_stage: negative stride");
@@ -596,7 +605,7 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
         }
         if (reach > VK_MRF_HALO) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: a resblock reaches further than 64 samples");
         if (reach > halo) halo = reach;
-        q.groups[r] = (a->channels / 32) * k * 2;
+        q.groups[r] = (a->channels / 32) * k * (f32 ? 4 : 2);
     }
     auto span = [&](int64_t cstride) -> int64_t { return ((int64_t)(a->channels - 1) * cstride + a->length) * 4; };
     const int64_t xb = span(a->x_cstride), ob = span(a->out_cstride);
@@ -608,10 +617,16 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
         if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_mrf_stage: out overlaps x");
     }
     q.x_bytes = (unsigned)xb; q.out_bytes = (unsigned)ob;
+    if (a->acc) {
+        const int64_t ab = span(a->acc_cstride);
+        if (ab > 0x7fffffffLL) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: one batch item's view spans more than 2 GiB");
+        q.acc_bytes = (unsigned)ab;
+    }
     q.halo = halo;                                       // columns recomputed on either side: the longest reach
     q.out_cols = vk_mrf_window(*G) - 2 * halo;
     dim3 grid((unsigned)((a->length + q.out_cols - 1) / q.out_cols), 1, (unsigned)a->batch);
-    int e = vk_launch_mrf_bf16(a->channels, q, grid, vk_mrf_lds_bytes(*G), (hipStream_t)stream);
+    int e = f32 ? vk_launch_mrf_f32(a->channels, single, q, grid, vk_mrf_f32_lds_bytes(*G), (hipStream_t)stream)
+                : vk_launch_mrf_bf16(a->channels, single, q, grid, vk_mrf_lds_bytes(*G), (hipStream_t)stream);
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: this channel count is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
     return VK_OK;

@@ -10,8 +10,12 @@
         return (int)hipGetLastError();                                                           \
     }
 
-int vk_launch_mrf_bf16(int channels, const MrfDev& q, dim3 grid, size_t lds, hipStream_t s)
+int vk_launch_mrf_bf16(int channels, bool single, const MrfDev& q, dim3 grid, size_t lds, hipStream_t s)
 {
+    if (single) {
+        VK_MRF_CASE(kMrf32s)
+        VK_MRF_CASE(kMrf64s)
+    }
     VK_MRF_CASE(kMrf32)
     VK_MRF_CASE(kMrf64)
     VK_MRF_CASE(kMrf128)

@@ -51,18 +51,21 @@ constexpr int VK_MRF_GUARD  = 32;                           // addressable colum
 struct MrfGeom { int wm, wn, nt, two, sum; };
 static constexpr MrfGeom kMrf32  = {1, 4, 4, 0, 1};         // 512-column window, 4 waves, one image (46 KB)
 static constexpr MrfGeom kMrf64  = {2, 4, 4, 0, 1};         // 512-column window, 8 waves, one image (83 KB)
+static constexpr MrfGeom kMrf32s = {1, 4, 4, 0, 0};         // the same windows for one resblock per launch: no
+static constexpr MrfGeom kMrf64s = {2, 4, 4, 0, 0};         // register copy for the sum, weights two taps ahead
 static constexpr MrfGeom kMrf128 = {4, 2, 4, 0, 0};         // 256-column window, 8 waves, one image (87 KB)
 static constexpr MrfGeom kMrf256 = {8, 1, 4, 0, 0};         // 128-column window, 8 waves, one image (101 KB)
-static inline const MrfGeom* vk_mrf_geom(int channels)
+// the widest launch a channel count has (`single`: the kernel for one resblock per launch)
+static inline const MrfGeom* vk_mrf_geom(int channels, bool single = false)
 {
-    return channels == 32 ? &kMrf32 : channels == 64 ? &kMrf64 : channels == 128 ? &kMrf128 :
-           channels == 256 ? &kMrf256 : nullptr;
+    return channels == 32 ? (single ? &kMrf32s : &kMrf32) : channels == 64 ? (single ? &kMrf64s : &kMrf64) :
+           channels == 128 ? &kMrf128 : channels == 256 ? &kMrf256 : nullptr;
 }
 static inline int vk_mrf_window(const MrfGeom& g) { return 32 * g.nt * g.wn; }
 
 struct MrfDev {
     vk_mrf_args a;
-    unsigned x_bytes, out_bytes;    // byte spans of one batch item's views
+    unsigned x_bytes, out_bytes, acc_bytes;    // byte spans of one batch item's views
     int halo, out_cols;             // recomputed columns on either side of a window; output columns per workgroup
     int groups[VK_MRF_MAX_BLOCKS];  // 64-lane x 16-byte groups per 32-row tile of a conv of block r: chunks * taps * 2
 };
@@ -243,18 +246,29 @@ mrf_stage_bf16_kernel(const MrfDev q)
         if (!TWO && blk + 1 < p.n_blocks) VK_MRF_SYNC();     // the next resblock's input replaces h
     }
 
-    // ---- out = sum / n_blocks for the window's output columns ----
+    // ---- out = (acc + sum) / navg for the window's output columns ----
     const __amdgpu_buffer_rsrc_t r_out = vk_rsrc(p.out + (int64_t)b * p.out_bstride, q.out_bytes);
-    const float nb = (float)p.n_blocks;
+    const __amdgpu_buffer_rsrc_t r_acc = vk_rsrc(p.acc ? p.acc + (int64_t)b * p.acc_bstride : p.x, p.acc ? q.acc_bytes : 0u);
+    const float nb = p.navg;
+    const bool scale = nb != 1.0f;                          // launch-uniform
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int c = col0 + 32 * n;
         const int t = tw + 32 * n;
         if (c >= q.halo && c < q.halo + q.out_cols && t < L) {
+            float av[16];
+            if (p.acc != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    av[r] = vk_bld(r_acc, 4 * (t + 4 * half * (int)p.acc_cstride),
+                                   (wm * 32 + (r & 3) + 8 * (r >> 2)) * (int)p.acc_cstride * 4);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + (r & 3) + 8 * (r >> 2);
-                const float v = SUM ? tot[n][r] / nb : xr[0][n][r];
+                float v = SUM ? tot[n][r] : xr[0][n][r];
+                if (p.acc != nullptr) v = av[r] + v;
+                if (scale) v = v / nb;
                 vk_bst(v, r_out, 4 * (t + 4 * half * (int)p.out_cstride), row * (int)p.out_cstride * 4);
             }
         }
@@ -262,4 +276,4 @@ mrf_stage_bf16_kernel(const MrfDev q)
 }
 
 // Returns hipSuccess / a HIP error, or -1 when there is no kernel for this channel count.
-int vk_launch_mrf_bf16(int channels, const MrfDev& q, dim3 grid, size_t lds, hipStream_t s);
+int vk_launch_mrf_bf16(int channels, bool single, const MrfDev& q, dim3 grid, size_t lds, hipStream_t s);

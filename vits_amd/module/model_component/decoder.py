@@ -68,17 +68,32 @@ class ResBlockPlan:
                                    PackedConv(c2.effective_weight(), c2.bias, device, dilation=1)))
         self.taps = k
         # A resblock of short kernels as ONE launch (the three pairs chained in registers / LDS):
-        # its pair launches wait on memory, and a workgroup of the chained form recomputes only
-        # `reach` columns per side.  Longer kernels (reach 36 / 60) lose more to the recompute than
-        # they save.  Only where the stage kernel takes one resblock per launch (128 channels);
-        # narrower stages run whole through it.
+        # its pair launches wait on memory or pay a prologue and an epilogue per pair, and a
+        # workgroup of the chained form recomputes only `reach` columns per side.  Longer kernels
+        # (reach 36 / 60) lose more to the recompute than they save.  bf16 matrix inputs: where the
+        # stage kernel takes one resblock per launch (128 / 256 channels; narrower stages run whole
+        # through it).  fp32: 32 and 64 channels.
         self.chain = None
-        mi = native.mrf_info(rb.channels, prec) if prec == native.PREC_BF16 else None
+        mi = native.mrf_info(rb.channels, prec) if prec in (native.PREC_BF16, native.PREC_F32) else None
         reach = sum((k - 1) // 2 * (d + 1) for d in rb.dilation) if (k % 2 == 1 and k >= 3) else 1 << 30
-        if (self.fused and mi is not None and os.environ.get("VITS_AMD_MRF_FUSION", "1") != "0"
+        if (mi is not None and os.environ.get("VITS_AMD_MRF_FUSION", "1") != "0"
+                and (self.fused or prec == native.PREC_F32)
                 and reach <= self.chain_max_reach and len(rb.dilation) <= native.MRF_MAX_PAIRS
                 and all((k - 1) // 2 * d <= 32 for d in rb.dilation)):
-            self.chain = [(k, self.pairs)]
+            same = (pi is not None and pi.rows_per_block == mi.rows_per_block and
+                    (pi.ck_bf16 == mi.ck_bf16 if prec == native.PREC_BF16 else pi.ck == mi.ck))
+            if self.fused and same:
+                chain_pairs = self.pairs                # the pair kernel's packing is the chain's
+            else:
+                def pk(c):
+                    w = c.effective_weight().to(device)
+                    if prec == native.PREC_BF16:
+                        return packing.pack_conv_weight_bf16(w, mi.ck_bf16, mi.rows_per_block)
+                    return packing.pack_conv_weight(w, mi.ck, mi.rows_per_block)
+                chain_pairs = [(pk(c1), c1.bias.detach().to(device=device, dtype=torch.float32).contiguous(),
+                                pk(c2), c2.bias.detach().to(device=device, dtype=torch.float32).contiguous(), d)
+                               for c1, c2, d in zip(rb.convs1, rb.convs2, rb.dilation)]
+            self.chain = [(k, chain_pairs)]
 
     chain_max_reach = 16
 
@@ -107,12 +122,14 @@ class ResBlockPlan:
         residual, or residual + accumulation over resblocks); earlier pairs update ``run_buf``
         (and ``tmp``).  ``before_final`` is called just before the launch that touches
         ``final_out`` / ``acc_in`` (where a concurrent branch orders itself after its predecessor)."""
-        if self.chain is not None and final_epi == native.EPI_RESID:
+        if self.chain is not None:
             if final_out.data_ptr() == x.data_ptr():
                 raise native.NativeError("resblock: the output buffer aliases the input")
             if before_final is not None:
                 before_final()
-            native.mrf_stage(x, final_out, self.chain, slope=LRELU_SLOPE)
+            native.mrf_stage(x, final_out, self.chain, slope=LRELU_SLOPE,
+                             acc=acc_in if final_epi != native.EPI_RESID else None,
+                             navg=navg if final_epi == native.EPI_RESID_AVG else 1.0)
             return final_out
         if self.fused:
             return self._run_fused(x, tmp, run_buf, final_out, final_epi,

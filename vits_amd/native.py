@@ -106,6 +106,8 @@ class MrfArgs(C.Structure):
         ("w2", (_fp * MRF_MAX_PAIRS) * MRF_MAX_BLOCKS),
         ("bias2", (_fp * MRF_MAX_PAIRS) * MRF_MAX_BLOCKS),
         ("slope", C.c_float), ("precision", C.c_int32),
+        ("acc", _fp), ("acc_bstride", C.c_int64), ("acc_cstride", C.c_int64),
+        ("navg", C.c_float),
     ]
 
 
@@ -476,29 +478,38 @@ def mrf_info(channels: int, precision: int):
     return _mrf_cache[key]
 
 
-def mrf_stage(x, out, blocks, *, slope):
-    """out = mean over resblocks of resblock(x) in one launch.  ``blocks``: per resblock
-    (taps, [(w1, bias1, w2, bias2, dilation) per pair]) with bf16 fragment-packed weights."""
+def mrf_stage(x, out, blocks, *, slope, acc=None, navg=None):
+    """out = (acc + sum over resblocks of resblock(x)) / navg in one launch (navg: the number of
+    resblocks unless given; acc: the sum carried from earlier launches of the stage, may be ``out``).
+    ``blocks``: per resblock (taps, [(w1, bias1, w2, bias2, dilation) per pair]) with
+    fragment-packed weights, bf16 (bf16 matrix inputs) or fp32 (the exact fp32 instruction)."""
     assert x.is_cuda and x.dtype == torch.float32 and out.dtype == torch.float32
     a = MrfArgs()
     a.x, a.x_bstride, a.x_cstride = _view(x)
     a.out, a.out_bstride, a.out_cstride = _view(out)
+    if acc is not None:
+        assert acc.dtype == torch.float32 and acc.shape == out.shape
+        a.acc, a.acc_bstride, a.acc_cstride = _view(acc)
+    a.navg = float(len(blocks)) if navg is None else float(navg)
     a.batch, a.channels, a.length = x.shape
     a.n_blocks, a.n_pairs = len(blocks), len(blocks[0][1])
     flops = 0.0
+    wdt = blocks[0][1][0][0].dtype
     for r, (taps, pairs) in enumerate(blocks):
         assert len(pairs) == a.n_pairs
         a.taps[r] = taps
         for j, (w1, b1, w2, b2, dil) in enumerate(pairs):
-            assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+            assert w1.dtype == wdt and w2.dtype == wdt and wdt in (torch.bfloat16, torch.float32)
             a.dilation[r][j] = dil
             a.w1[r][j], a.w2[r][j] = w1.data_ptr(), w2.data_ptr()
             a.bias1[r][j] = b1.data_ptr() if b1 is not None else None
             a.bias2[r][j] = b2.data_ptr() if b2 is not None else None
             flops += 4.0 * x.shape[0] * x.shape[2] * x.shape[1] * x.shape[1] * taps
-    a.slope, a.precision = slope, PREC_BF16
+    a.slope, a.precision = slope, (PREC_BF16 if wdt == torch.bfloat16 else PREC_F32)
     L, sp = lib(), stream_ptr(x.device)
-    check(_timed(f"mrf_stage_bf16[c{x.shape[1]}]", flops, 4.0 * (x.numel() + out.numel()), x.device,
+    nbytes = 4.0 * (x.numel() + out.numel() + (acc.numel() if acc is not None else 0))
+    family = f"mrf_stage{'_bf16' if wdt == torch.bfloat16 else ''}[c{x.shape[1]}]"
+    check(_timed(family, flops, nbytes, x.device,
                  lambda: L.vk_mrf_stage(C.byref(a), sp), f"B{x.shape[0]} L{x.shape[2]} c{x.shape[1]}"),
           "vk_mrf_stage")
 
