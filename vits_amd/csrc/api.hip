@@ -468,6 +468,7 @@ extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
     q.c.lds_stride = TN + 64;
     q.c.groups_per_mt = q.c.nchunk * a->taps * (bf16 ? ck / 16 : ck / 8);
     q.w2 = a->w2; q.bias2 = a->bias2; q.groups2 = q.c.groups_per_mt;
+    q.c.stamps = g_stamps;
     const int TNO = TN - VK_PAIR_OVERLAP;
     dim3 grid((unsigned)((a->length + TNO - 1) / TNO), 1, (unsigned)a->batch);
     const size_t lds = bf16 ? pair_bf16_lds(*G16) : (size_t)a->channels * q.c.lds_stride * sizeof(float);

@@ -47,6 +47,7 @@ resblock_pair_bf16_kernel(const PairDev q)
     const int h2   = (p.taps - 1) >> 1;
 
     const float* xb = p.x + (int64_t)b * p.x_bstride;
+    vk_stamp(d, 0);         // diagnostic build: phase time stamps (tools/pair_stamps.py)
     Bf16Stager<NW, NJ, CK, XP, true> stg;
     stg.init(d, xb, t0, lane, w);
     stg.issue(d, 0);
@@ -83,10 +84,12 @@ resblock_pair_bf16_kernel(const PairDev q)
         char* buf = lds8 + (chunk & 1) * XBUF;
         stg.store(d, chunk, buf);
         __syncthreads();
+        if (chunk == 0) vk_stamp(d, 1);
         if (chunk + 1 < NCH) stg.issue(d, chunk + 1);
         bf16_taps<A_REP, B_REP, KS, XP>(acc, a, aptr, buf + bcol1, p.taps, p.dilation * XP,
                                         w2ptr, chained && chunk + 1 == NCH);
     }
+    vk_stamp(d, 2);
 
     // ---- second conv's weights: in the ring already, or requested before h is handed over ----
 #pragma unroll
@@ -142,14 +145,17 @@ resblock_pair_bf16_kernel(const PairDev q)
         }
     }
     __syncthreads();
+    vk_stamp(d, 3);
 
     // ------------------------------ second convolution ------------------------------
     const int bcol2 = (wn * TNW + l31) * HP + half * 16;
     for (int chunk = 0; chunk < NCH; ++chunk)
         bf16_taps<A_REP, B_REP, KS, HP>(acc, a, aptr, lds8 + bcol2 + chunk * (CK * 2), p.taps, HP);
+    vk_stamp(d, 5);
 
 #pragma unroll
     for (int m = 0; m < A_REP; ++m) pair_epilogue<B_REP, EPI, TNO, true>(d, acc[m], b, t0, mt0 + m, wn, half, l31);
+    vk_stamp(d, 6);
 }
 
 struct PairGeomBf16 { int a_rep, b_rep, wm, wn; };
