@@ -8,8 +8,10 @@ import torch
 sys.path.insert(0, ".")
 from vits_amd import native, packing
 
-native.use_diagnostic_library()
 C, K, DIL, B, L = (int(a) for a in sys.argv[1:6])
+if len(sys.argv) > 6:
+    native.DIAG_LIB_PATH = sys.argv[6]
+native.use_diagnostic_library()
 dev = torch.device("cuda:0")
 lib = native.lib()
 lib.vk_debug_set_stamps.argtypes = [ctypes.c_void_p]
@@ -46,6 +48,12 @@ for name, a, b in (("load + stage chunk 0", 0, 1), ("conv 1 (4 chunks)", 1, 2), 
     dd = us[:, b] - us[:, a]
     print(f"{name:22s} mean {dd.mean():7.2f}  p10 {np.percentile(dd, 10):7.2f}  p50 {np.percentile(dd, 50):7.2f}  "
           f"p90 {np.percentile(dd, 90):7.2f}  max {dd.max():7.2f}")
+f = s[:, 4].astype(np.uint64)
+if f.any():     # a build with -DVK_PAIR_FINE: wave 0's time inside the first convolution's chunk loop
+    parts = [((f >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.float64) / 100.0 for i in range(4)]
+    for name, v in zip(("wait for the chunk's loads (chunks 1..)", "convert + LDS store (chunks 1..)",
+                        "barrier (chunks 1..)", "tap loops (all chunks)"), parts):
+        print(f"  {name:42s} mean {v.mean():6.2f} us  p90 {np.percentile(v, 90):6.2f}")
 hw = s[:, 7] & 0xffffffff
 xcc = s[:, 7] >> 32
 cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)

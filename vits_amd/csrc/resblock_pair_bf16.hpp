@@ -14,6 +14,44 @@
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build with -DVK_PAIR_FINE only (tools/pair_stamps.py): wave 0's time inside the first
+// convolution's chunk loop, split into waiting for a chunk's loads, converting and storing it,
+// the barrier, and the tap loops.  Empty otherwise.  Two more timing switches of that build
+// (results invalid): -DVK_PAIR_NOLOAD loads only the first chunk, -DVK_PAIR_ONE_WG asks for enough
+// LDS that one workgroup fits a CU.
+#if defined(VK_DIAG) && defined(VK_PAIR_FINE)
+struct PairFine {
+    unsigned long long t[4] = {0, 0, 0, 0}, m = 0;
+    __device__ __forceinline__ void mark() { m = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void lap(int i, bool count = true)
+    {
+        const unsigned long long n = __builtin_amdgcn_s_memrealtime();
+        if (count) t[i] += n - m;
+        m = n;
+    }
+    __device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ void flush(const ConvDev& d)
+    {
+        if (d.stamps != nullptr && threadIdx.x == 0) {      // four 16-bit fields of 10 ns ticks in stamp slot 4
+            const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            d.stamps[(size_t)lin * 8 + 4] = (t[0] & 0xffff) | ((t[1] & 0xffff) << 16) | ((t[2] & 0xffff) << 32) | ((t[3] & 0xffff) << 48);
+        }
+    }
+};
+#else
+struct PairFine {
+    __device__ __forceinline__ void mark() {}
+    __device__ __forceinline__ void lap(int, bool = true) {}
+    __device__ __forceinline__ void wait_loads() {}
+    __device__ __forceinline__ void flush(const ConvDev&) {}
+};
+#endif
+#if defined(VK_DIAG) && defined(VK_PAIR_NOLOAD)
+constexpr bool kPairLoadAllChunks = false;
+#else
+constexpr bool kPairLoadAllChunks = true;
+#endif
+
 template <int A_REP, int B_REP, int WM, int WN, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 resblock_pair_bf16_kernel(const PairDev q)
@@ -171,6 +209,9 @@ static inline size_t pair_bf16_lds(const PairGeomBf16& G)
     const int TN = 32 * G.b_rep * G.wn, C = 32 * G.a_rep * G.wm, nch = C / 32;
     const size_t x = (size_t)(nch < 2 ? nch : 2) * (TN + 64) * (32 * 2 + 16);
     const size_t h = (size_t)(TN + VK_PAIR_OVERLAP) * (C * 2 + 16);
+#if defined(VK_DIAG) && defined(VK_PAIR_ONE_WG)
+    return 100 * 1024;
+#endif
     return x > h ? x : h;
 }
 
