@@ -209,8 +209,10 @@ int vk_resblock_pair(const vk_pair_args* a, void* stream);
  *   a = in_conv(x) + cond ; acts = tanh(a[:H]) * sigmoid(a[H:]) ; rs = res_skip(acts)
  *   x_out = (x + rs[:H]) * mask ; skip (+)= rs[H:]         (wn.py:68-83)
  *   last layer: out = (skip + rs) * mask                    (wn.py:85-86)
- * acts stays in LDS.  fp32 only, hidden = 192 (vk_wn_query reports the packing geometry;
- * other widths use two vk_conv1d launches).  x_out must not overlap x.                 */
+ * acts stays in LDS.  hidden = 192 (vk_wn_query reports the packing geometry: ck and
+ * rows_per_block for VK_PREC_F32, ck_bf16 and rows_per_block for VK_PREC_BF16, whose roundings
+ * are those of two vk_conv1d launches; other widths use two vk_conv1d launches).
+ * x_out must not overlap x.                                                            */
 typedef struct {
     const float* x;       int64_t x_bstride;    int64_t x_cstride;     /* layer input [B, H, L] */
     const float* w_in;                                                 /* in-conv, rows in (a_q, b_q) pair order */
@@ -222,6 +224,7 @@ typedef struct {
     int32_t batch, hidden, length, taps, dilation;
     int32_t first, last;                                               /* first: skip starts at zero */
     const int64_t* cond_index;  int32_t cond_rows;                     /* as vk_conv_args.bias_index: row of a per-speaker table */
+    int32_t precision;                                                 /* VK_PREC_F32 or VK_PREC_BF16 (packed weight format too) */
 } vk_wn_args;
 
 int vk_wn_query(int hidden, vk_tile_info* info);

@@ -459,6 +459,74 @@ def test_fused_wn_layer(B, T, lens, dil):
                         taps=k, dilation=dil, first=True, last=False)
 
 
+@pytest.mark.parametrize("B,T,lens,dil", [(2, 50, (50, 21), 1), (3, 129, (129, 1, 77), 1), (1, 300, (300,), 2),
+                                          (16, 860, tuple(range(860, 700, -10)), 1),      # 64-column windows
+                                          (40, 862, tuple(range(862, 822, -1)), 1)])      # 128-column windows
+def test_bf16_fused_wn_layer(B, T, lens, dil):
+    """The one-launch layer with bf16 matrix inputs against a reference with the roundings made
+    explicit (x, weights and gated activations rounded to bf16, everything else fp32)."""
+    H, k = 192, 5
+    wi = native.wn_info(H)
+    assert wi is not None and wi.ck_bf16 == 32
+    mask = (torch.arange(T).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)).float()
+    x = _rand(B, H, T, seed=131)
+    w_in = _rand(2 * H, H, k, seed=132) / (H * k) ** 0.5
+    cond = _rand(B, 2 * H, seed=133)
+    w_rs = _rand(2 * H, H, 1, seed=134) / H ** 0.5
+    b_rs = _rand(2 * H, seed=135)
+    skip0 = _rand(B, H, T, seed=136)
+    a = F.conv1d(_r16(x), _r16(w_in), None, padding=(k - 1) * dil // 2, dilation=dil) + cond.unsqueeze(-1)
+    acts = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])
+    rs = F.conv1d(_r16(acts), _r16(w_rs), b_rs)
+    order = packing.pair_row_order(H)
+    p_in = packing.pack_conv_weight_bf16(w_in, wi.ck_bf16, wi.rows_per_block, order).to(DEV)
+    p_rs = packing.pack_conv_weight_bf16(w_rs, wi.ck_bf16, 32).to(DEV)
+    xd, md = x.to(DEV), mask.to(DEV)
+
+    def close16(got, ref, what):        # a gated activation on a bf16 rounding boundary may fall either way
+        got = got.cpu()
+        assert torch.isfinite(got).all(), what
+        err = (got - ref).abs()
+        scale = max(1.0, ref.abs().max().item())
+        assert err.max().item() <= 6e-3 * scale, f"{what}: {err.max().item():.3e}"
+        assert err.mean().item() <= 2e-5 * scale, f"{what}: mean {err.mean().item():.3e}"
+
+    for first in (True, False):
+        x_out = torch.full((B, H, T), float("nan"), device=DEV)
+        skip = skip0.to(DEV).clone()
+        native.wn_layer(xd, p_in, cond.to(DEV), 2 * H, p_rs, b_rs.to(DEV), x_out, skip, md,
+                        taps=k, dilation=dil, first=first, last=False)
+        close16(x_out, (x + rs[:, :H]) * mask.unsqueeze(1), "WN layer residual half")
+        close16(skip, rs[:, H:] if first else skip0 + rs[:, H:], "WN layer skip half")
+    w_last = _rand(H, H, 1, seed=137) / H ** 0.5
+    p_last = packing.pack_conv_weight_bf16(w_last, wi.ck_bf16, 32).to(DEV)
+    out = torch.full((B, H, T), float("nan"), device=DEV)
+    skip = skip0.to(DEV).clone()
+    native.wn_layer(xd, p_in, cond.to(DEV), 2 * H, p_last, b_rs[:H].to(DEV), out, skip, md,
+                    taps=k, dilation=dil, first=False, last=True)
+    close16(out, (skip0 + F.conv1d(_r16(acts), _r16(w_last), b_rs[:H])) * mask.unsqueeze(1), "WN last layer")
+    # the same layer as two launches of the bf16 convolution kernel (gate epilogue, then the 1x1
+    # conv with the residual / skip epilogue): same roundings, same order of sums
+    ti = native.tile_info(native.TILE_PAIR)
+    g_in = packing.pack_conv_weight_bf16(w_in, ti.ck_bf16, ti.rows_per_block, order).to(DEV)
+    acts_d = torch.empty(B, H, T, device=DEV)
+    native.conv1d(xd, g_in, acts_d, c_in=H, c_out=2 * H, taps=k, dilation=dil, pad=(k - 1) * dil // 2,
+                  tile=native.TILE_PAIR, epilogue=native.EPI_GATE, bias=cond.to(DEV), bias_bstride=2 * H, hidden=H)
+    from vits_amd.engine import choose_tile
+    t2 = choose_tile(2 * H)
+    ti2 = native.tile_info(t2)
+    g_rs = packing.pack_conv_weight_bf16(w_rs, ti2.ck_bf16, ti2.rows_per_block).to(DEV)
+    x2 = xd.clone()
+    skip2 = skip0.to(DEV).clone()
+    native.conv1d(acts_d, g_rs, x2, c_in=H, c_out=2 * H, taps=1, dilation=1, pad=0, tile=t2,
+                  epilogue=native.EPI_WN_MID, bias=b_rs.to(DEV), res=x2, out2=skip2, mask=md, first=False, hidden=H)
+    x_out = torch.empty(B, H, T, device=DEV)
+    skip = skip0.to(DEV).clone()
+    native.wn_layer(xd, p_in, cond.to(DEV), 2 * H, p_rs, b_rs.to(DEV), x_out, skip, md,
+                    taps=k, dilation=dil, first=False, last=False)
+    assert torch.equal(x_out, x2) and torch.equal(skip, skip2)
+
+
 def test_split_conv_over_a_wide_dynamic_range():
     """Slices keep fp32's exponent range: channels scaled from 1e-18 to 1e+18 (weights scaled
     inversely so the products stay O(1)) give the same relative accuracy as unit-scale data."""

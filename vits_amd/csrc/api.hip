@@ -11,6 +11,7 @@
 #include "wn_layer.hpp"
 #include "mrf_stage.hpp"
 #include "mrf_stage_f32.hpp"
+#include "wn_layer_bf16.hpp"
 #include "api_internal.hpp"
 
 static thread_local char g_err[512] = "";
@@ -486,7 +487,7 @@ extern "C" int vk_wn_query(int hidden, vk_tile_info* info)
     info->rows_per_block = 64;
     info->time_tile = 64;
     info->a_rep = 2;
-    info->ck_bf16 = 0;
+    info->ck_bf16 = 32;
     info->ck_split = 0;
     info->max_blocks = 0;
     return VK_OK;
@@ -513,9 +514,18 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
         const char* o0 = (const char*)a->x_out;  const char* o1 = o0 + (int64_t)(a->batch - 1) * a->xo_bstride * 4 + ob;
         if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_wn_layer: x_out overlaps x");
     }
-    // 64-column windows unless that leaves most CUs without a workgroup
-    const int b_rep = ((int64_t)a->batch * ((a->length + 63) / 64) >= 512) ? 2 : 1;
+    const bool bf16 = a->precision == VK_PREC_BF16;
+    if (!bf16 && a->precision != VK_PREC_F32) return vk_fail(VK_E_UNSUPPORTED, "vk_wn_layer: built for VK_PREC_F32 and VK_PREC_BF16");
+    // 64-column windows unless that leaves most CUs without a workgroup (bf16 inputs: 128 columns
+    // once every CU gets several workgroups of them; diagnostic build: VK_WN_BREP forces the choice)
+    const int64_t win64 = (int64_t)a->batch * ((a->length + 63) / 64);
+    static const int force_brep = diag_env("VK_WN_BREP", 0);
+    // measured, reverse flow with bf16 inputs, 32 / 64 / 128 columns: 16 x 862 frames 0.63 / 0.61 / 0.77 ms,
+    // 64 x 862 frames 1.99 / 1.93 / 1.67 ms
+    const int b_rep = (force_brep && (bf16 || force_brep <= 2)) ? force_brep
+                    : bf16 ? (win64 < 128 ? 1 : win64 < 768 ? 2 : 4) : (win64 < 512 ? 1 : 2);
     const int TN = 32 * b_rep;
+    const int ck = bf16 ? 32 : VK_WN_CK;
     WnDev q;
     memset(&q, 0, sizeof(q));
     vk_conv_args& c = q.c.a;
@@ -530,9 +540,9 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
     c.first = a->first; c.hidden = a->hidden;
     c.bias_index = a->cond_index; c.bias_rows = a->cond_rows;
     q.c.x_bytes = (unsigned)xb; q.c.out_bytes = (unsigned)ob; q.c.res_bytes = (unsigned)xb; q.c.out2_bytes = (unsigned)sb;
-    q.c.nchunk = a->hidden / VK_WN_CK;
+    q.c.nchunk = a->hidden / ck;
     static const int no_vec = diag_env("VK_NO_VEC", 0);
-    const int vec = !no_vec && ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) &&
+    const int vec = !bf16 && !no_vec && ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) &&
                     (a->length % 4 == 0);
     if (vec) {
         const int padv = (c.pad + 3) & ~3;
@@ -543,13 +553,18 @@ extern "C" int vk_wn_layer(const vk_wn_args* a, void* stream)
         q.c.xw = TN + halo;
     }
     q.c.lds_stride = TN + 64;
-    q.c.groups_per_mt = q.c.nchunk * a->taps * (VK_WN_CK / 8);
-    q.w_rs = a->w_rs; q.bias_rs = a->bias_rs; q.groups_rs = q.c.nchunk * (VK_WN_CK / 8);
+    q.c.groups_per_mt = q.c.nchunk * a->taps * (bf16 ? ck / 16 : ck / 8);
+    q.w_rs = a->w_rs; q.bias_rs = a->bias_rs; q.groups_rs = q.c.nchunk * (bf16 ? ck / 16 : ck / 8);
     q.last = a->last;
     dim3 grid((unsigned)((a->length + TN - 1) / TN), 1, (unsigned)a->batch);
-    const size_t xs = (size_t)2 * VK_WN_CK * (TN + 64), as = (size_t)a->hidden * (TN + 4);
-    const size_t lds = (xs > as ? xs : as) * sizeof(float);
-    int e = vk_launch_wn_layer(b_rep, a->last ? 1 : 0, vec, q, grid, lds, (hipStream_t)stream);
+    int e;
+    if (bf16) {
+        e = vk_launch_wn_layer_bf16(b_rep, a->last ? 1 : 0, q, grid, wn_bf16_lds(b_rep), (hipStream_t)stream);
+    } else {
+        const size_t xs = (size_t)2 * VK_WN_CK * (TN + 64), as = (size_t)a->hidden * (TN + 4);
+        const size_t lds = (xs > as ? xs : as) * sizeof(float);
+        e = vk_launch_wn_layer(b_rep, a->last ? 1 : 0, vec, q, grid, lds, (hipStream_t)stream);
+    }
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_wn_layer: this combination is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
     return VK_OK;

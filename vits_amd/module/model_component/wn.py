@@ -7,9 +7,9 @@ speaker_id_embedded)`` and the same ``state_dict`` keys (``in_resblocks.{i}``,
 
 Per layer the reference runs a k-tap conv (H -> 2H), adds the layer's slice of the speaker
 conditioning, gates tanh*sigmoid, runs a 1x1 conv (H -> 2H, last layer H) and splits the
-result into a masked residual update and a skip accumulation.  For hidden = 192 in fp32 that
-is one launch per layer (csrc/wn_layer.hpp: the gated activations stay in LDS between the two
-convolutions).  Otherwise it is two launches of the convolution kernel: conv + conditioning
+result into a masked residual update and a skip accumulation.  For hidden = 192 that can be
+one launch per layer (csrc/wn_layer.hpp, csrc/wn_layer_bf16.hpp: the gated activations stay in LDS
+between the two convolutions; fp32 and bf16 matrix inputs).  Otherwise it is two launches of the convolution kernel: conv + conditioning
 bias + gate in one epilogue, and 1x1 conv + residual/skip/mask in the other.  The conditioning 1x1 conv on the [B, G, 1]
 speaker vector is one wavefront-reduced GEMV for all layers, with the in-conv biases
 folded in.
@@ -30,6 +30,11 @@ class WNPlan:
     """Packed weights of one WN stack on one device."""
 
     fused_max_columns = 12288
+    # bf16 inputs: one launch per layer at every size (reverse flow, one launch / two launches per layer:
+    # 1 x 258 frames 0.45 / 0.72 ms, 4 x 862 0.49 / 0.74, 16 x 862 0.61 / 0.94, 64 x 862 1.67 / 2.41);
+    # the bf16 convolution kernel has no split channel loop for the two-launch form to win with
+    fused_max_columns_bf16 = int(os.environ.get("VITS_AMD_WN_FUSED_MAX_BF16", 1 << 30))
+    fused_min_columns_bf16 = int(os.environ.get("VITS_AMD_WN_FUSED_MIN_BF16", 0))
     fused_min_columns = 4096     # below: two launches per layer, each with its channel loop split over workgroups
 
     def __init__(self, wn: "WN", device):
@@ -38,7 +43,9 @@ class WNPlan:
         self.hidden, self.n_layers = H, n
         self.in_convs, self.rs_convs = [], []
         # one launch per layer where the fused kernel exists (VITS_AMD_WN_FUSION=0 disables it)
-        wi = native.wn_info(H) if (precision() == native.PREC_F32
+        prec = precision()
+        self.bf16 = prec == native.PREC_BF16
+        wi = native.wn_info(H) if (prec in (native.PREC_F32, native.PREC_BF16)
                                    and os.environ.get("VITS_AMD_WN_FUSION", "1") != "0") else None
         k = wn.kernel_size
         self.fused = wi is not None and all((k - 1) * wn.dilation_rate ** i <= 56 for i in range(n))
@@ -52,7 +59,11 @@ class WNPlan:
             cond_bias[2 * H * i:2 * H * (i + 1)] += m.bias.detach().to(device)
             r = wn.res_skip_layers[i]
             self.rs_convs.append(PackedConv(r.effective_weight(), r.bias, device))
-            if self.fused:
+            if self.fused and self.bf16:
+                self.fused_w.append((
+                    packing.pack_conv_weight_bf16(m.effective_weight().to(device), wi.ck_bf16, wi.rows_per_block, order),
+                    packing.pack_conv_weight_bf16(r.effective_weight().to(device), wi.ck_bf16, 32)))
+            elif self.fused:
                 self.fused_w.append((
                     packing.pack_conv_weight(m.effective_weight().to(device), wi.ck, wi.rows_per_block, order),
                     packing.pack_conv_weight(r.effective_weight().to(device), wi.ck, 32)))
@@ -79,7 +90,9 @@ class WNPlan:
         # give the one-launch layer a few dozen workgroups, each a serial loop over 960 channel taps,
         # while the two-launch form splits that loop over workgroups; in between the one-launch
         # layer's fewer dependent launches win; beyond, its 6-wave workgroups fill the SIMDs less evenly.
-        if self.fused and (self.fused_min_columns < B * T <= self.fused_max_columns or not native.SPLIT_SMALL_LAUNCHES):
+        fused_max = self.fused_max_columns_bf16 if self.bf16 else self.fused_max_columns
+        fused_min = self.fused_min_columns_bf16 if self.bf16 else self.fused_min_columns
+        if self.fused and (fused_min < B * T <= fused_max or not native.SPLIT_SMALL_LAUNCHES):
             other = torch.empty_like(x)             # layers ping-pong: a layer's output may not land on its input
             for i in range(self.n_layers):
                 ic, rc = self.in_convs[i], self.rs_convs[i]

@@ -86,6 +86,7 @@ class WnArgs(C.Structure):
         ("batch", C.c_int32), ("hidden", C.c_int32), ("length", C.c_int32), ("taps", C.c_int32),
         ("dilation", C.c_int32), ("first", C.c_int32), ("last", C.c_int32),
         ("cond_index", _fp), ("cond_rows", C.c_int32),
+        ("precision", C.c_int32),
     ]
 
 
@@ -543,11 +544,14 @@ def wn_layer(x, w_in, cond, cond_bstride, w_rs, bias_rs, x_out, skip, mask, *, t
     a.mask = mask.data_ptr()
     a.batch, a.hidden, a.length = x.shape
     a.taps, a.dilation, a.first, a.last = taps, dilation, int(first), int(last)
+    assert w_in.dtype == w_rs.dtype and w_in.dtype in (torch.float32, torch.bfloat16)
+    bf16 = w_in.dtype == torch.bfloat16
+    a.precision = PREC_BF16 if bf16 else PREC_F32
     B, H, T = x.shape
     flops = 2.0 * B * T * H * (2 * H * taps + (H if last else 2 * H))
     nbytes = 4.0 * B * H * T * (3 if last else 5)
     L, sp = lib(), stream_ptr(x.device)
-    check(_timed(f"wn_layer[{'last' if last else 'mid'}]", flops, nbytes, x.device,
+    check(_timed(f"wn_layer{'_bf16' if bf16 else ''}[{'last' if last else 'mid'}]", flops, nbytes, x.device,
                  lambda: L.vk_wn_layer(C.byref(a), sp), f"B{B} L{T} h{H} k{taps} d{dilation}"), "vk_wn_layer")
 
 
