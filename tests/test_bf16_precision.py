@@ -127,3 +127,25 @@ def test_precision_switch_rebuilds_plans(sd, golden_dir):
     assert torch.equal(a, c)
     assert not torch.equal(a, b)
     assert (a - g1["wav"]).abs().max().item() <= 1e-4
+
+
+def test_bf16_voice_conversion_at_full_size(sd, bf16_mode):
+    """BASELINE config 4 at its real size (64 utterances of 862 frames, bf16 matrix inputs):
+    first, middle and last item against the CPU oracle run on each item alone (items of a batch
+    do not interact anywhere on the path), plus ragged lengths in the same batch."""
+    from oracle import vits_oracle as O
+    B, T = 64, 862
+    gen = HotPathGenerator(100)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV).eval()
+    spec = synth.power_spectrogram(SEED, "cfg4.spec", B, T)
+    lens = torch.full((B,), T, dtype=torch.int64)
+    lens[37], lens[63] = 700, 431                                  # two shorter items
+    spec = spec * synth.length_mask(lens, T)
+    src, tgt = synth.speaker_ids(SEED, "cfg4.src", B), synth.speaker_ids(SEED, "cfg4.tgt", B)
+    eps = synth.latent(SEED, "cfg4.eps", B, T)
+    wav = gen.voice_conversion(spec.to(DEV), lens.to(DEV), src.to(DEV), tgt.to(DEV), noise=eps.to(DEV)).cpu()
+    assert wav.shape == (B, 1, T * 256) and torch.isfinite(wav).all()
+    for i in (0, 37, 63):
+        ref = O.voice_conversion(spec[i:i + 1], lens[i:i + 1], src[i:i + 1], tgt[i:i + 1], sd, eps[i:i + 1])
+        _report(wav[i:i + 1], ref, f"bf16 voice conversion B=64, item {i}")      # the whole padded item
