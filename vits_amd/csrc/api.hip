@@ -638,11 +638,6 @@ extern "C" int vk_mrf_stage(const vk_mrf_args* a, void* stream)
         if (ab > 0x7fffffffLL) return vk_fail(VK_E_UNSUPPORTED, "vk_mrf_stage: one batch item's view spans more than 2 GiB");
         q.acc_bytes = (unsigned)ab;
     }
-    {
-        static const int align = diag_env("VK_MRF_ALIGN", 1);       // diagnostic build: halo rounded up to a multiple
-        halo = (halo + align - 1) / align * align;
-        if (halo > VK_MRF_HALO) halo = VK_MRF_HALO;
-    }
     q.halo = halo;                                       // columns recomputed on either side: the longest reach
     q.out_cols = vk_mrf_window(*G) - 2 * halo;
     dim3 grid((unsigned)((a->length + q.out_cols - 1) / q.out_cols), 1, (unsigned)a->batch);
