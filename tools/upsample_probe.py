@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Diagnostic: time the polyphase transposed convolution of one decoder stage (needs a GPU).
-upsample_probe.py C_IN C_OUT STRIDE B L      (VK_DEBUG_SKIP=1 drops the epilogue: timing only)"""
+upsample_probe.py C_IN C_OUT STRIDE B L [fp32|bf16] [library]     (VK_DEBUG_SKIP=1 drops the epilogue: timing only)"""
 import sys
 import torch
 sys.path.insert(0, ".")
 from vits_amd import native, packing
 
+if len(sys.argv) > 7:
+    native.DIAG_LIB_PATH = sys.argv[7]
 native.use_diagnostic_library()      # build it with `python -m vits_amd.build --diag`
 from vits_amd.engine import choose_tile
 
@@ -15,7 +17,10 @@ wt = torch.randn(cin, cout, 2 * s) / (cin * 2) ** 0.5
 poly = packing.transposed_to_polyphase(wt, s)
 tile = choose_tile(poly.shape[0])
 ti = native.tile_info(tile)
-wp = packing.pack_conv_weight(poly, ti.ck, ti.rows_per_block, packing.polyphase_row_order(cout, s)).to(dev)
+bf16 = len(sys.argv) > 6 and sys.argv[6] == "bf16"
+order = packing.polyphase_row_order(cout, s)
+wp = (packing.pack_conv_weight_bf16(poly, ti.ck_bf16, ti.rows_per_block, order) if bf16
+      else packing.pack_conv_weight(poly, ti.ck, ti.rows_per_block, order)).to(dev)
 x = torch.randn(B, cin, L, device=dev)
 bias = torch.randn(cout, device=dev)
 out = torch.empty(B, cout, L * s, device=dev)
