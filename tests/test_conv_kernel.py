@@ -419,6 +419,61 @@ def test_split_conv_matches_fp32(cin, cout, k, dil, B, L, act, monkeypatch):
         _close(out2, (ref + res.double()).float(), "split residual")
 
 
+@pytest.mark.parametrize("ch,k,dil,B,L", [
+    (32, 3, 1, 2, 1),            # a single sample
+    (32, 11, 5, 2, 37),          # halo longer than the signal
+    (32, 7, 3, 1, 244),          # exactly one workgroup's worth of outputs
+    (32, 7, 3, 2, 245),          # one column into the second workgroup, odd length
+    (32, 3, 5, 2, 2000),
+    (64, 11, 1, 1, 116),         # one 64-channel workgroup
+    (64, 11, 5, 2, 463),
+    (64, 3, 3, 3, 1200),
+])
+def test_sliced_fp32_fused_resblock_pair(ch, k, dil, B, L, monkeypatch):
+    """The fused pair in sliced-fp32 arithmetic: as close to fp64 as the fp32 kernels, and the
+    same bits as the two sliced convolution launches it replaces (same operations in the same order)."""
+    monkeypatch.setattr(native, "SPLIT_SMALL_LAUNCHES", False)      # one accumulation chain in the yardstick launches
+    x = _rand(B, ch, L, seed=151)
+    w1 = _rand(ch, ch, k, seed=152) / (ch * k) ** 0.5
+    w2 = _rand(ch, ch, k, seed=153) / (ch * k) ** 0.5
+    b1, b2 = _rand(ch, seed=154), _rand(ch, seed=155)
+    h = F.conv1d(F.leaky_relu(x.double(), 0.1), w1.double(), b1.double(), padding=(k - 1) * dil // 2, dilation=dil)
+    ref = (F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2) + x.double())
+    pi = native.pair_info(ch, native.PREC_F32_SPLIT)
+    assert pi is not None and pi.ck_split == 16
+    p1 = packing.pack_conv_weight_split(w1.to(DEV), pi.ck_split, pi.rows_per_block)
+    p2 = packing.pack_conv_weight_split(w2.to(DEV), pi.ck_split, pi.rows_per_block)
+    xd, b1d, b2d = x.to(DEV), b1.to(DEV), b2.to(DEV)
+    out = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.resblock_pair(xd, p1, b1d, p2, b2d, out, taps=k, dilation=dil, epilogue=native.EPI_RESID, slope=0.1)
+    _close(out, ref.float(), "sliced pair")
+    # the two launches: conv1 stored, conv2 with the residual epilogue
+    tile = choose_tile(ch)
+    q1, q2 = _pack_split(w1, tile), _pack_split(w2, tile)
+    hbuf = torch.empty(B, ch, L, device=DEV)
+    two = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.conv1d(xd, q1, hbuf, c_in=ch, c_out=ch, taps=k, dilation=dil, pad=(k - 1) * dil // 2, tile=tile,
+                  epilogue=native.EPI_STORE, bias=b1d, act_in=True, in_slope=0.1)
+    native.conv1d(hbuf, q2, two, c_in=ch, c_out=ch, taps=k, dilation=1, pad=(k - 1) // 2, tile=tile,
+                  epilogue=native.EPI_RESID, bias=b2d, res=xd, act_in=True, in_slope=0.1)
+    assert torch.equal(out, two), (out - two).abs().max().item()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    accb = _rand(B, ch, L, seed=156)
+    acc = accb.to(DEV).clone()
+    native.resblock_pair(xd, p1, b1d, p2, b2d, acc, taps=k, dilation=dil, epilogue=native.EPI_RESID_ACC, slope=0.1, acc=acc)
+    _close(acc, accb + ref.float(), "sliced pair + accumulate")
+    acc = accb.to(DEV).clone()
+    native.resblock_pair(xd, p1, b1d, p2, b2d, acc, taps=k, dilation=dil, epilogue=native.EPI_RESID_AVG, slope=0.1,
+                         acc=acc, navg=3.0)
+    _close(acc, (accb + ref.float()) / 3.0, "sliced pair + accumulate + mean")
+    wide = torch.zeros(B, ch + 3, L, device=DEV)
+    wide[:, 3:] = xd
+    out2 = torch.full((B, ch, L), float("nan"), device=DEV)
+    native.resblock_pair(wide[:, 3:], p1, b1d, p2, b2d, out2, taps=k, dilation=dil, epilogue=native.EPI_RESID, slope=0.1)
+    assert torch.equal(out2, out)
+
+
 @pytest.mark.parametrize("B,T,lens,dil", [(2, 50, (50, 21), 1), (3, 129, (129, 1, 77), 1), (1, 300, (300,), 2),
                                           (16, 860, tuple(range(860, 700, -10)), 1)])
 def test_fused_wn_layer(B, T, lens, dil):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: time the fused resblock pair of one shape (needs a GPU).
-  pair_probe.py C K DIL B L [bf16|fp32] [iterations] [diagnostic library]"""
+  pair_probe.py C K DIL B L [bf16|fp32|split] [iterations] [diagnostic library]
+With `split` also the two sliced convolution launches the pair replaces."""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -13,12 +14,13 @@ if len(sys.argv) > 8:                      # a diagnostic build: path of the lib
     native.DIAG_LIB_PATH = sys.argv[8]
     native.use_diagnostic_library()
 dev = torch.device("cuda:0")
-P = native.PREC_BF16 if prec == "bf16" else native.PREC_F32
+P = {"bf16": native.PREC_BF16, "split": native.PREC_F32_SPLIT}.get(prec, native.PREC_F32)
 pi = native.pair_info(C, P)
 pack = (lambda w: packing.pack_conv_weight_bf16(w, pi.ck_bf16, pi.rows_per_block)) if prec == "bf16" else \
+       (lambda w: packing.pack_conv_weight_split(w, pi.ck_split, pi.rows_per_block)) if prec == "split" else \
        (lambda w: packing.pack_conv_weight(w, pi.ck, pi.rows_per_block))
-w1 = pack(torch.randn(C, C, K) / (C * K) ** 0.5).to(dev)
-w2 = pack(torch.randn(C, C, K) / (C * K) ** 0.5).to(dev)
+wa, wb = (torch.randn(C, C, K) / (C * K) ** 0.5).to(dev), (torch.randn(C, C, K) / (C * K) ** 0.5).to(dev)
+w1, w2 = pack(wa), pack(wb)
 b1, b2 = torch.randn(C, device=dev), torch.randn(C, device=dev)
 x = torch.randn(B, C, L, device=dev)
 out = torch.empty_like(x)
@@ -27,6 +29,37 @@ out = torch.empty_like(x)
 def run():
     native.resblock_pair(x, w1, b1, w2, b2, out, taps=K, dilation=DIL, epilogue=native.EPI_RESID, slope=0.1)
 
+
+def timed(f):
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+if prec == "split":
+    from vits_amd.engine import choose_tile
+    tile = choose_tile(C)
+    ti = native.tile_info(tile)
+    q1 = packing.pack_conv_weight_split(wa, ti.ck_split, ti.rows_per_block)
+    q2 = packing.pack_conv_weight_split(wb, ti.ck_split, ti.rows_per_block)
+    h, out2 = torch.empty_like(x), torch.empty_like(x)
+
+    def two():
+        native.conv1d(x, q1, h, c_in=C, c_out=C, taps=K, dilation=DIL, pad=(K - 1) * DIL // 2, tile=tile,
+                      epilogue=native.EPI_STORE, bias=b1, act_in=True, in_slope=0.1)
+        native.conv1d(h, q2, out2, c_in=C, c_out=C, taps=K, dilation=1, pad=(K - 1) // 2, tile=tile,
+                      epilogue=native.EPI_RESID, bias=b2, res=x, act_in=True, in_slope=0.1)
+    ms2 = timed(two)
+    run()
+    torch.cuda.synchronize()
+    print(f"  two sliced convolution launches: {ms2 * 1e3:8.1f} us, max abs difference to the pair {(out - out2).abs().max().item()}")
 
 for _ in range(3):
     run()

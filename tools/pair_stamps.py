@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-workgroup phase times of one fused bf16 resblock-pair launch (needs a GPU and the
-diagnostic library, `python -m vits_amd.build --diag`).   pair_stamps.py C K DIL B L"""
+diagnostic library, `python -m vits_amd.build --diag`).   pair_stamps.py C K DIL B L [library | -] [bf16|split]"""
 import ctypes
 import sys
 import numpy as np
@@ -9,14 +9,16 @@ sys.path.insert(0, ".")
 from vits_amd import native, packing
 
 C, K, DIL, B, L = (int(a) for a in sys.argv[1:6])
-if len(sys.argv) > 6:
+if len(sys.argv) > 6 and sys.argv[6] != "-":
     native.DIAG_LIB_PATH = sys.argv[6]
+split = len(sys.argv) > 7 and sys.argv[7] == "split"
 native.use_diagnostic_library()
 dev = torch.device("cuda:0")
 lib = native.lib()
 lib.vk_debug_set_stamps.argtypes = [ctypes.c_void_p]
-pi = native.pair_info(C, native.PREC_BF16)
-pack = lambda w: packing.pack_conv_weight_bf16(w, pi.ck_bf16, pi.rows_per_block).to(dev)
+pi = native.pair_info(C, native.PREC_F32_SPLIT if split else native.PREC_BF16)
+pack = (lambda w: packing.pack_conv_weight_split(w.to(dev), pi.ck_split, pi.rows_per_block)) if split else \
+       (lambda w: packing.pack_conv_weight_bf16(w, pi.ck_bf16, pi.rows_per_block).to(dev))
 w1, w2 = pack(torch.randn(C, C, K) / (C * K) ** 0.5), pack(torch.randn(C, C, K) / (C * K) ** 0.5)
 b1, b2 = torch.randn(C, device=dev), torch.randn(C, device=dev)
 x = torch.randn(B, C, L, device=dev)

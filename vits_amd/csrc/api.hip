@@ -12,6 +12,7 @@
 #include "mrf_stage.hpp"
 #include "mrf_stage_f32.hpp"
 #include "wn_layer_bf16.hpp"
+#include "resblock_pair_split.hpp"
 #include "api_internal.hpp"
 
 static thread_local char g_err[512] = "";
@@ -376,6 +377,13 @@ static const PairGeom* pair_geom(int channels)
     return nullptr;
 }
 
+static const PairGeomSplit* pair_geom_split(int channels)
+{
+    if (channels == 32) return &kPairSplit32;
+    if (channels == 64) return &kPairSplit64;
+    return nullptr;
+}
+
 static const PairGeomBf16* pair_geom_bf16(int channels)
 {
     if (channels == 32) return &kPairBf16_32;
@@ -397,6 +405,15 @@ extern "C" int vk_pair_query(int channels, int precision, vk_tile_info* info)
         info->a_rep = G->a_rep;
         return VK_OK;
     }
+    if (precision == VK_PREC_F32_SPLIT) {
+        const PairGeomSplit* G = pair_geom_split(channels);
+        if (!G) return vk_fail(VK_E_UNSUPPORTED, "vk_pair_query: no fused sliced-fp32 kernel for this channel count");
+        info->ck = 0; info->ck_bf16 = 0; info->ck_split = VK_SPLIT_CK; info->max_blocks = 0;
+        info->rows_per_block = 32;
+        info->time_tile = 32 * G->b_rep * G->wn - VK_PAIR_OVERLAP;
+        info->a_rep = 1;
+        return VK_OK;
+    }
     const PairGeom* G = pair_geom(channels);
     if (!G || precision != VK_PREC_F32) return vk_fail(VK_E_UNSUPPORTED, "vk_pair_query: no fused kernel for this channel count");
     info->ck = G->ck;
@@ -415,11 +432,12 @@ extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
     if (!a->x || !a->w1 || !a->w2 || !a->out) return vk_fail(VK_E_ARG, "vk_resblock_pair: null x / w1 / w2 / out pointer");
     if (a->batch <= 0 || a->length <= 0 || a->dilation <= 0) return vk_fail(VK_E_ARG, "vk_resblock_pair: non-positive size");
     if (a->batch > 65535) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: batch > 65535");
-    const bool bf16 = a->precision == VK_PREC_BF16;
-    if (a->precision != VK_PREC_F32 && !bf16) return vk_fail(VK_E_ARG, "vk_resblock_pair: bad precision id");
-    const PairGeom* G = bf16 ? nullptr : pair_geom(a->channels);
+    const bool bf16 = a->precision == VK_PREC_BF16, split = a->precision == VK_PREC_F32_SPLIT;
+    if (a->precision != VK_PREC_F32 && !bf16 && !split) return vk_fail(VK_E_ARG, "vk_resblock_pair: bad precision id");
+    const PairGeom* G = (bf16 || split) ? nullptr : pair_geom(a->channels);
     const PairGeomBf16* G16 = bf16 ? pair_geom_bf16(a->channels) : nullptr;
-    if (!G && !G16) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: no fused kernel for this channel count and precision");
+    const PairGeomSplit* GS = split ? pair_geom_split(a->channels) : nullptr;
+    if (!G && !G16 && !GS) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: no fused kernel for this channel count and precision");
     if (a->taps < 1 || !(a->taps & 1) || a->taps - 1 > VK_PAIR_OVERLAP)
         return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: taps must be odd and at most 13");
     const int h2 = (a->taps - 1) / 2;
@@ -439,8 +457,8 @@ extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
         const char* o0 = (const char*)a->out; const char* o1 = o0 + (int64_t)(a->batch - 1) * a->out_bstride * 4 + ob;
         if (o0 < x1 && x0 < o1) return vk_fail(VK_E_ARG, "vk_resblock_pair: out overlaps x");
     }
-    const int TN = bf16 ? 32 * G16->b_rep * G16->wn : 32 * G->b_rep * G->wn;
-    const int ck = bf16 ? 32 : G->ck;
+    const int TN = bf16 ? 32 * G16->b_rep * G16->wn : split ? 32 * GS->b_rep * GS->wn : 32 * G->b_rep * G->wn;
+    const int ck = bf16 ? 32 : split ? VK_SPLIT_CK : G->ck;
     PairDev q;
     memset(&q, 0, sizeof(q));
     vk_conv_args& c = q.c.a;
@@ -456,7 +474,7 @@ extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
     q.c.x_bytes = (unsigned)xb; q.c.out_bytes = (unsigned)ob; q.c.res_bytes = (unsigned)xb; q.c.out2_bytes = (unsigned)ab;
     q.c.nchunk = a->channels / ck;
     static const int no_vec = diag_env("VK_NO_VEC", 0);
-    const int vec = !no_vec && !bf16 && ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) &&
+    const int vec = !no_vec && !bf16 && !split && ((uintptr_t)a->x % 16 == 0) && (a->x_bstride % 4 == 0) && (a->x_cstride % 4 == 0) &&
                     (a->length % 4 == 0);
     if (vec) {
         const int padv = (c.pad + 3) & ~3;
@@ -467,14 +485,16 @@ extern "C" int vk_resblock_pair(const vk_pair_args* a, void* stream)
         q.c.xw = TN + halo;
     }
     q.c.lds_stride = TN + 64;
-    q.c.groups_per_mt = q.c.nchunk * a->taps * (bf16 ? ck / 16 : ck / 8);
+    q.c.groups_per_mt = q.c.nchunk * a->taps * (bf16 ? ck / 16 : split ? 3 * (ck / 16) : ck / 8);
     q.w2 = a->w2; q.bias2 = a->bias2; q.groups2 = q.c.groups_per_mt;
     q.c.stamps = g_stamps;
     const int TNO = TN - VK_PAIR_OVERLAP;
     dim3 grid((unsigned)((a->length + TNO - 1) / TNO), 1, (unsigned)a->batch);
-    const size_t lds = bf16 ? pair_bf16_lds(*G16) : (size_t)a->channels * q.c.lds_stride * sizeof(float);
-    int e = bf16 ? vk_launch_pair_bf16(a->channels, a->epilogue, q, grid, lds, (hipStream_t)stream)
-                 : vk_launch_pair(a->channels, a->epilogue, vec, q, grid, lds, (hipStream_t)stream);
+    const size_t lds = bf16 ? pair_bf16_lds(*G16) : split ? pair_split_lds(*GS)
+                            : (size_t)a->channels * q.c.lds_stride * sizeof(float);
+    int e = bf16  ? vk_launch_pair_bf16(a->channels, a->epilogue, q, grid, lds, (hipStream_t)stream)
+          : split ? vk_launch_pair_split(a->channels, a->epilogue, q, grid, lds, (hipStream_t)stream)
+                  : vk_launch_pair(a->channels, a->epilogue, vec, q, grid, lds, (hipStream_t)stream);
     if (e == -1) return vk_fail(VK_E_UNSUPPORTED, "vk_resblock_pair: this combination is not built");
     if (e != 0) return vk_fail(VK_E_LAUNCH, hipGetErrorString((hipError_t)e));
     return VK_OK;

@@ -48,7 +48,7 @@ class ResBlockPlan:
         prec = precision()
         pi = None if mode == "none" else native.pair_info(rb.channels, prec)
         k = rb.kernel_size
-        wide_ok = prec == native.PREC_BF16 or rb.channels <= 32 or mode == "all"
+        wide_ok = prec in (native.PREC_BF16, native.PREC_F32_SPLIT) or rb.channels <= 32 or mode == "all"
         self.fused = (pi is not None and wide_ok and k % 2 == 1 and k <= 13
                       and all((k - 1) * d <= 52 for d in rb.dilation))
         for j, d in enumerate(rb.dilation):
@@ -58,6 +58,8 @@ class ResBlockPlan:
                     w = c.effective_weight().to(device)
                     if prec == native.PREC_BF16:
                         return packing.pack_conv_weight_bf16(w, pi.ck_bf16, pi.rows_per_block)
+                    if prec == native.PREC_F32_SPLIT:
+                        return packing.pack_conv_weight_split(w, pi.ck_split, pi.rows_per_block)
                     return packing.pack_conv_weight(w, pi.ck, pi.rows_per_block)
 
                 def bs(c):

@@ -455,10 +455,11 @@ def resblock_pair(x, w1, bias1, w2, bias2, out, *, taps, dilation, epilogue, slo
     a.taps, a.dilation, a.epilogue = taps, dilation, epilogue
     a.slope, a.navg = slope, navg
     assert w1.dtype == w2.dtype and w1.dtype in (torch.float32, torch.bfloat16)
-    a.precision = PREC_BF16 if w1.dtype == torch.bfloat16 else PREC_F32
+    # the packed weight format names the matrix-core input precision (sliced fp32 is stored as bf16 slices)
+    a.precision = getattr(w1, "vk_precision", PREC_BF16 if w1.dtype == torch.bfloat16 else PREC_F32)
     ch = x.shape[1]
     flops = 2.0 * x.shape[0] * x.shape[2] * ch * ch * taps * 2
-    family = f"resblock_pair{'_bf16' if a.precision == PREC_BF16 else ''}[c{ch},{_EPI_NAMES[epilogue]}]"
+    family = f"resblock_pair{('', '_bf16', '_split')[a.precision]}[c{ch},{_EPI_NAMES[epilogue]}]"
     L, sp = lib(), stream_ptr(x.device)
     detail = f"B{x.shape[0]} L{x.shape[2]} c{ch} k{taps} d{dilation}"
     nbytes = 4.0 * (x.numel() + out.numel() + (acc.numel() if acc is not None else 0))
