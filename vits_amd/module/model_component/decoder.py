@@ -48,7 +48,11 @@ class ResBlockPlan:
         prec = precision()
         pi = None if mode == "none" else native.pair_info(rb.channels, prec)
         k = rb.kernel_size
-        wide_ok = prec in (native.PREC_BF16, native.PREC_F32_SPLIT) or rb.channels <= 32 or mode == "all"
+        # sliced fp32 (six matrix instructions per product), measured at 16 x 862 frames, one launch
+        # against two, at 3 / 7 / 11 taps: 32 channels 0.40 / 0.60 / 0.88 ms against 0.64 / 0.83 / 1.05;
+        # 64 channels 0.61 / 1.15 / 1.67 against 0.71 / 1.11 / 1.52 (the matrix work dominates there)
+        wide_ok = (prec == native.PREC_BF16 or rb.channels <= 32 or mode == "all"
+                   or (prec == native.PREC_F32_SPLIT and k <= 3))
         self.fused = (pi is not None and wide_ok and k % 2 == 1 and k <= 13
                       and all((k - 1) * d <= 52 for d in rb.dilation))
         for j, d in enumerate(rb.dilation):
