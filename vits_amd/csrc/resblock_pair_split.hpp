@@ -4,23 +4,33 @@
 //   out = conv2(lrelu(h)) + x    taps k, dilation 1      (/root/reference/module/model_component/decoder.py:49-58)
 //
 // Every operand of a matrix instruction is an fp32 value cut into three bf16 slices, a product is
-// the six largest slice products (conv_split.hpp has the error bound).  For 32 and 64 channels,
-// where two launches of the sliced convolution kernel move 20 bytes per element for 12 k matrix
-// flops and are bound by memory: here x is cut once while it is staged, h is cut once when it is
-// handed over in LDS, and neither h nor a second copy of x touches HBM.
+// the six largest slice products (conv_split.hpp has the error bound).  Built for 32 and 64
+// channels, where two launches of the sliced convolution kernel move 20 bytes per tensor element
+// (x, h twice, the residual, out) and at 32 channels are bound by that: here x is cut once while
+// it is staged, h is cut once when it is handed over in LDS, and h never touches HBM.
 //
 // A workgroup owns every channel of a window of TN columns.  The image in LDS is channel-minor,
 // the three slices of a column side by side: [column][slice][channel] in bf16, PITCH = 3 * 2 * C + 16
 // bytes per column (an odd multiple of 16: conflict-free 16-byte fragment reads).  h is written
 // over the x image once every wave has left the first convolution.  Weights are packed by
-// packing.pack_conv_weight_split with 16-channel chunks: per 32-row tile and (chunk, tap) three
-// 16-byte fragments per lane (hi, mid, lo), streamed from L2 one tap ahead.  The arithmetic of
-// an output element is that of two conv_split_kernel launches, operation for operation.
+// packing.pack_conv_weight_split with 16-channel chunks: per 32-row tile and (chunk, tap) step three
+// 16-byte fragments per lane (hi, mid, lo), streamed from L2 four steps ahead.  The arithmetic of
+// an output element is that of two conv_split_kernel launches, operation for operation, so the
+// results are the same bits.
 #pragma once
 #include "conv_split.hpp"
 #include "resblock_pair.hpp"
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Diagnostic build only (-DVK_DIAG -DVK_PS_ABL=n, results invalid): 1 = the step loop fetches no weight
+// fragments, 2 = it reads no B fragments from LDS.  (With both, a 32-channel 11-tap launch still takes
+// 1090 of 1250 us: the loops are bound by the matrix pipe, at the clock it holds under bf16 load.)
+#if defined(VK_DIAG) && defined(VK_PS_ABL)
+constexpr int kPairSplitAbl = VK_PS_ABL;
+#else
+constexpr int kPairSplitAbl = 0;
+#endif
 
 template <int B_REP, int WM, int WN, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
@@ -146,14 +156,14 @@ resblock_pair_split_kernel(const PairDev q)
                 bt += tap_step;
             }
             bf16x8 bn[3][B_REP];
-#if defined(VK_DIAG) && defined(VK_PS_ABL) && (VK_PS_ABL & 2)
+            if (kPairSplitAbl & 2) {
 #pragma unroll
-            for (int n = 0; n < B_REP; ++n)
+                for (int n = 0; n < B_REP; ++n)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) bn[s][n] = bf[s][n];
-#else
-            read_b(bn, bt);
-#endif
+                    for (int s = 0; s < 3; ++s) bn[s][n] = bf[s][n];
+            } else {
+                read_b(bn, bt);
+            }
             // The six slice products of a column tile form a dependent chain (smallest terms first, as
             // conv_split_kernel); the chains of the B_REP column tiles are interleaved, so that a matrix
             // instruction never follows the one whose result it accumulates onto.
@@ -165,10 +175,10 @@ resblock_pair_split_kernel(const PairDev q)
                 for (int n = 0; n < B_REP; ++n)
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][kA[t]], bf[kB[t]][n], acc[n], 0, 0, 0);
             // (past the end of the stream: the next tile's, or the zero groups that end a packed tensor)
-#if !(defined(VK_DIAG) && defined(VK_PS_ABL) && (VK_PS_ABL & 1))
+            if (!(kPairSplitAbl & 1)) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) a[S][s] = ap[64 * (3 * (RING + S) + s)];
-#endif
+                for (int s = 0; s < 3; ++s) a[S][s] = ap[64 * (3 * (RING + S) + s)];
+            }
 #pragma unroll
             for (int n = 0; n < B_REP; ++n)
 #pragma unroll
@@ -240,13 +250,13 @@ resblock_pair_split_kernel(const PairDev q)
     vk_stamp(d, 6);
 }
 
+// Four waves of 32 rows x 64 columns, two workgroups per CU.  Measured against these (16 x 862 frames,
+// 3 / 7 / 11 taps): eight waves of 32 x 32 (twice the weight fragments per matrix instruction)
+// 523 / 845 / 1146 us against 467 / 754 / 1014 at 32 channels; 128-column windows at 32 channels, four
+// workgroups per CU: 514 / 821 / 1094 us.
 struct PairGeomSplit { int b_rep, wm, wn; };
-#ifndef VK_PS32
-#define VK_PS32 2, 1, 4
-#define VK_PS64 2, 2, 2
-#endif
-static constexpr PairGeomSplit kPairSplit32 = {VK_PS32};        // 256-column window, 66.5 KB of LDS
-static constexpr PairGeomSplit kPairSplit64 = {VK_PS64};        // 128-column window, 76.8 KB
+static constexpr PairGeomSplit kPairSplit32 = {2, 1, 4};        // 256-column window, 66.5 KB of LDS
+static constexpr PairGeomSplit kPairSplit64 = {2, 2, 2};        // 128-column window, 76.8 KB
 
 static inline size_t pair_split_lds(const PairGeomSplit& G)
 {
