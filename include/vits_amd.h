@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 9
+#define VK_ABI_VERSION 10
 
 #define VK_OK            0
 #define VK_E_ARG        -1   /* null pointer / non-positive size / inconsistent strides */
@@ -196,12 +196,15 @@ typedef struct {
     int32_t taps, dilation;                     /* taps odd, <= 13; (taps-1)*dilation <= 52 */
     int32_t epilogue;                           /* VK_EPI_RESID, VK_EPI_RESID_ACC, VK_EPI_RESID_AVG */
     float   slope, navg;
-    int32_t precision;                          /* VK_PREC_F32 (32/64 channels) or VK_PREC_BF16 (32/64/128) */
+    int32_t precision;                          /* VK_PREC_F32 / VK_PREC_F32_SPLIT (32/64 channels) or VK_PREC_BF16 (32..256) */
 } vk_pair_args;
 
 /* Packing geometry of the fused kernel for this channel width and precision
- * (VK_E_UNSUPPORTED if none): weights are packed with `ck` (fp32) or `ck_bf16` (bf16) and
- * `rows_per_block`; time_tile is the number of output columns a workgroup keeps.       */
+ * (VK_E_UNSUPPORTED if none): weights are packed with `ck` (fp32), `ck_bf16` (bf16) or
+ * `ck_split` (sliced fp32: the three-slice format of the sliced convolution kernel) and
+ * `rows_per_block`; time_tile is the number of output columns a workgroup keeps.  In
+ * sliced fp32 the result is bit-identical to the two vk_conv1d launches (VK_EPI_STORE, then
+ * the residual epilogue) it replaces.                                                  */
 int vk_pair_query(int channels, int precision, vk_tile_info* info);
 int vk_resblock_pair(const vk_pair_args* a, void* stream);
 
