@@ -422,6 +422,32 @@ def main():
                     failures.append(f"{prec}: differs from the CPU oracle by {others[prec]['parity_max_abs']:.3e}")
             engine.set_precision(args.precision)
             line["other_precisions"] = others
+        if world == 1 and args.workload == "batch" and not args.no_other_precisions:
+            # The same step with the resblocks of a decoder stage on streams of their own (the small-batch
+            # path, forced on): the launches of one branch fill the tails of another's.  Not the timed region:
+            # launches that share the GPU cannot be bracketed one by one, so `roofline` needs the serial order.
+            before_env = os.environ.get("VITS_AMD_BRANCH_STREAMS")
+            os.environ["VITS_AMD_BRANCH_STREAMS"] = "on"
+            try:
+                for _ in range(2):
+                    w3 = step()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    w3 = step()
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t1) / args.steps
+            finally:
+                if before_env is None:
+                    del os.environ["VITS_AMD_BRANCH_STREAMS"]
+                else:
+                    os.environ["VITS_AMD_BRANCH_STREAMS"] = before_env
+            line["overlapped_branches"] = {
+                "ms_per_step": 1e3 * dt, "value": B * T * HOP / SAMPLE_RATE / dt, "steps": args.steps,
+                "switch": "VITS_AMD_BRANCH_STREAMS=on",
+                "same_bits_as_timed_output": bool(torch.equal(w3, wav)),
+                "note": "resblocks of a stage on three streams; the default keeps them on one stream above "
+                        "2048 frames in flight so that every launch's device time is its own"}
         if world == 1 and not args.no_other_configs:
             from tools import bench_configs
             line["other_configs"] = bench_configs.run(dev, SEED)

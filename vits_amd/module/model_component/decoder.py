@@ -273,8 +273,9 @@ class Decoder(nn.Module):
     # output, so each can run on a stream of its own; the last launches are chained by events in
     # the reference's summation order (decoder.py:119-125), which keeps the result bit-identical.
     # Used with few utterances in flight, where one convolution does not fill 256 CUs.  At large
-    # sizes the streams are worth 0-2 % (measured at batch 16) and per-launch device times stop
-    # being attributable to one kernel, so large batches run the resblocks one after another.
+    # sizes the streams are worth 1-3 % (16 x 862 frames: fp32 66.7 -> 65.0 ms, bf16 inputs 12.26 ->
+    # 12.05, sliced fp32 49.3 -> 48.8; VITS_AMD_BRANCH_STREAMS=on) but per-launch device times stop
+    # being attributable to one kernel, so by default large batches run the resblocks one after another.
     concurrent_branch_frames = 2048         # use branch streams when batch * frames is at most this
 
     def _branches_concurrent(self, batch, frames):
