@@ -474,6 +474,42 @@ def test_sliced_fp32_fused_resblock_pair(ch, k, dil, B, L, monkeypatch):
     assert torch.equal(out2, out)
 
 
+def test_sliced_fp32_fused_pair_random_shapes(monkeypatch):
+    """Random (channels, taps, dilation, batch, length) within the kernel's limits, 1 .. 13 taps: the same
+    bits as the two sliced convolution launches (weight ring wrap-around, window edges, lengths around the
+    window size)."""
+    monkeypatch.setattr(native, "SPLIT_SMALL_LAUNCHES", False)
+    g = torch.Generator().manual_seed(4242)
+    for case in range(24):
+        ch = (32, 64)[int(torch.randint(0, 2, (1,), generator=g))]
+        k = (1, 3, 5, 7, 9, 11, 13)[int(torch.randint(0, 7, (1,), generator=g))]
+        dmax = 52 // (k - 1) if k > 1 else 8
+        dil = int(torch.randint(1, min(dmax, 8) + 1, (1,), generator=g))
+        B = int(torch.randint(1, 4, (1,), generator=g))
+        tno = native.pair_info(ch, native.PREC_F32_SPLIT).time_tile
+        L = int(torch.randint(1, 3 * tno + 40, (1,), generator=g)) if case % 3 else tno * (1 + case % 2) + (case % 5) - 2
+        x = torch.randn(B, ch, L, generator=g)
+        w1 = torch.randn(ch, ch, k, generator=g) / (ch * k) ** 0.5
+        w2 = torch.randn(ch, ch, k, generator=g) / (ch * k) ** 0.5
+        b1, b2 = torch.randn(ch, generator=g).to(DEV), torch.randn(ch, generator=g).to(DEV)
+        pi = native.pair_info(ch, native.PREC_F32_SPLIT)
+        p1 = packing.pack_conv_weight_split(w1.to(DEV), pi.ck_split, pi.rows_per_block)
+        p2 = packing.pack_conv_weight_split(w2.to(DEV), pi.ck_split, pi.rows_per_block)
+        xd = x.to(DEV)
+        out = torch.full((B, ch, L), float("nan"), device=DEV)
+        native.resblock_pair(xd, p1, b1, p2, b2, out, taps=k, dilation=dil, epilogue=native.EPI_RESID, slope=0.1)
+        tile = choose_tile(ch)
+        q1, q2 = _pack_split(w1, tile), _pack_split(w2, tile)
+        hbuf = torch.empty(B, ch, L, device=DEV)
+        two = torch.full((B, ch, L), float("nan"), device=DEV)
+        native.conv1d(xd, q1, hbuf, c_in=ch, c_out=ch, taps=k, dilation=dil, pad=(k - 1) * dil // 2, tile=tile,
+                      epilogue=native.EPI_STORE, bias=b1, act_in=True, in_slope=0.1)
+        native.conv1d(hbuf, q2, two, c_in=ch, c_out=ch, taps=k, dilation=1, pad=(k - 1) // 2, tile=tile,
+                      epilogue=native.EPI_RESID, bias=b2, res=xd, act_in=True, in_slope=0.1)
+        assert torch.isfinite(out).all(), (ch, k, dil, B, L)
+        assert torch.equal(out, two), (ch, k, dil, B, L, (out - two).abs().max().item())
+
+
 @pytest.mark.parametrize("B,T,lens,dil", [(2, 50, (50, 21), 1), (3, 129, (129, 1, 77), 1), (1, 300, (300,), 2),
                                           (16, 860, tuple(range(860, 700, -10)), 1)])
 def test_fused_wn_layer(B, T, lens, dil):
